@@ -1,0 +1,69 @@
+"""ctypes binding of oracle/libqa_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, nowhere else:
+the product path (qaray_amd/) must never route through the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqa_oracle.so")
+REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+
+
+class Counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("casts_normal", C.c_uint64), ("casts_shadow", C.c_uint64),
+                ("bvh_nodes", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "oracle"], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.qa_oracle_render.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_void_p, C.c_void_p,
+                                                                       C.c_void_p, C.c_int, C.POINTER(Counters)]
+        L.qa_oracle_halton.argtypes = [C.c_int, C.c_int]
+        L.qa_oracle_halton.restype = C.c_float
+        L.qa_oracle_rng_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.qa_oracle_rng_stream.restype = None
+        _lib = L
+    return _lib
+
+
+def render(blob, region, spp, max_bounce=5, seed=0x51A7A7, threads=0, spp_max=None):
+    """blob: numpy uint8 flat scene; region (x0,y0,x1,y1) -> (rgb[h,w,3], depth[h,w], ns[h,w], Counters)."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    x0, y0, x1, y1 = region
+    h, w = y1 - y0, x1 - x0
+    rgb = np.zeros((h, w, 3), np.float32)
+    depth = np.zeros((h, w), np.float32)
+    ns = np.zeros((h, w), np.uint32)
+    cnt = Counters()
+    spp_min = spp
+    spp_max = spp if spp_max is None else spp_max
+    rc = lib().qa_oracle_render(blob.ctypes.data, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed,
+                                rgb.ctypes.data, depth.ctypes.data, ns.ctypes.data, threads, C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(f"qa_oracle_render failed: {rc}")
+    return rgb, depth, ns, cnt
+
+
+def halton(i, base):
+    return float(lib().qa_oracle_halton(i, base))
+
+
+def rng_stream(seed, pixel, n):
+    out = np.zeros(n, np.float32)
+    lib().qa_oracle_rng_stream(seed, pixel, n, out.ctypes.data)
+    return out
