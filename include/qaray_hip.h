@@ -1,0 +1,92 @@
+/* qaray_hip.h — C ABI of the MI355X hot path (libqaray_hip.so, gfx950 only).
+ *
+ * The reference has no FFI: its hot path is reached through in-process C++ virtual calls
+ * (SURVEY.md §8b).  This header is the boundary a maintainer of the reference would bind from
+ * Renderer::ThreadRender; each entry point names the reference interface it stands in for
+ * (paths in the reference repo).  Plain pointers and sizes only; one host thread per context;
+ * every call returns QA_OK (0) or a negative QA_E* code (include/qaray_host.h) and never throws.
+ * The library owns all device memory behind the opaque handle; callers own every buffer they
+ * pass in.  There is NO CPU fallback: without a gfx950 device qa_ctx_create fails.
+ *
+ *   qa_ctx_create / destroy        Renderer::Renderer / Terminate      src/renderers/renderer.cpp:67-70,293-298
+ *   qa_scene_upload                Renderer::ComputeScene (scene side)  src/renderers/renderer.cpp:71-113
+ *   qa_scene_upload_device         same, blob already in HBM (after an RCCL broadcast); the
+ *                                  reference instead re-parses the XML on every rank
+ *                                                                       src/renderers/Renderer_MPI.cpp:54
+ *   qa_render_region[_device]      Renderer::ThreadRender -> PixelRender over a pixel region:
+ *                                  camera ray, Scene::TraceNodeNormal, Material::Shade,
+ *                                  Light::Illuminate/GenLight::Shadow, SuperSamplerHalton
+ *                                                                       src/renderers/renderer.cpp:302-423
+ *   qa_request_stop / qa_clear_stop   tasking::signal_stop / signal_start  src/tasking/parallel_for.cpp:70-73
+ *   qa_get_counters                (no counterpart: the reference only prints wall-clock)
+ *   qa_get_kernel_time             Renderer::StartTimer/StopTimer       src/renderers/renderer.cpp:42-63
+ */
+#ifndef QARAY_HIP_H
+#define QARAY_HIP_H
+
+#include <stdint.h>
+
+#include "qaray_host.h" /* QA_OK / QA_E* */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qa_ctx qa_ctx;
+
+typedef struct qa_counters {
+  uint64_t samples;        /* camera paths started (1 sample = 1 iteration of PixelRender's loop) */
+  uint64_t casts_normal;   /* closest-hit casts: camera + secondary rays */
+  uint64_t casts_shadow;   /* any-hit casts */
+  uint64_t bvh_nodes;      /* BVH nodes popped (only counted by stats launches, else 0) */
+  uint64_t tri_tests;      /* triangle tests   (only counted by stats launches, else 0) */
+  uint64_t pixels;         /* pixels completed */
+} qa_counters;
+
+/* flags for qa_render_region* */
+#define QA_RENDER_STATS 1u  /* also count BVH nodes / triangle tests (slower kernel variant) */
+
+int qa_ctx_create(int device_id, qa_ctx **out);
+int qa_ctx_destroy(qa_ctx *ctx);
+
+/* Upload a flattened scene (include/qa_flat_scene.h) from host memory / adopt a copy of one that
+ * already sits in device memory.  Replaces any previous scene of the context. */
+int qa_scene_upload(qa_ctx *ctx, const void *host_blob, uint64_t nbytes);
+int qa_scene_upload_device(qa_ctx *ctx, const void *device_blob, uint64_t nbytes);
+
+/* Render pixels [x0,x1) x [y0,y1) of the scene's image.  Outputs are region-local, row-major:
+ * rgb (y1-y0)*(x1-x0)*3 floats of LINEAR mean radiance (sRGB/quantisation stay in FrameBuffer),
+ * depth: hit distance of sample 0 (1e30 on a miss), nsamples: samples taken (0 = pixel skipped
+ * because a stop was requested).  Pixel (i,j) always uses RNG stream qa_pixel_seed(seed,
+ * j*width+i) (include/qa_seed.h), so any partition of the image gives identical pixels.
+ * The host variant synchronises and copies back; the device variant writes device buffers and
+ * only enqueues work on `hip_stream` (a hipStream_t, NULL = the context's own stream). */
+int qa_render_region(qa_ctx *ctx, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
+                     int max_bounce, uint32_t seed, uint32_t flags, float *rgb, float *depth,
+                     uint32_t *nsamples);
+int qa_render_region_device(qa_ctx *ctx, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
+                            int max_bounce, uint32_t seed, uint32_t flags, float *d_rgb,
+                            float *d_depth, uint32_t *d_nsamples, void *hip_stream);
+/* Wait for everything enqueued by this context. */
+int qa_synchronize(qa_ctx *ctx);
+
+int qa_request_stop(qa_ctx *ctx);
+int qa_clear_stop(qa_ctx *ctx);
+
+/* Counters accumulated since the last reset (synchronises the context first). */
+int qa_get_counters(qa_ctx *ctx, qa_counters *out);
+int qa_reset_counters(qa_ctx *ctx);
+/* Sum of the integrator kernel's durations (HIP events recorded around each launch, on the
+ * stream it was launched on) and the number of launches since the last reset; synchronises. */
+int qa_get_kernel_time(qa_ctx *ctx, double *total_ms, uint64_t *launches);
+int qa_reset_kernel_time(qa_ctx *ctx);
+
+/* Launch geometry (0 = library default). blocks_per_cu * CUs persistent workgroups of `threads`. */
+int qa_set_launch_config(qa_ctx *ctx, int blocks_per_cu, int threads_per_block);
+
+const char *qa_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QARAY_HIP_H */

@@ -1,0 +1,525 @@
+// qa_capi.hip — extern "C" surface of libqaray_hip.so (include/qaray_hip.h): context, scene
+// upload (blob -> device tables), launches of the integrator kernel, counters and timing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "qa_kernel.h"
+#include "qaray_hip.h"
+
+using namespace qa;
+
+static thread_local std::string g_err;
+static int Fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return Fail(QA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct qa_ctx {
+  int device = 0;
+  int numCUs = 0;
+  hipStream_t stream = nullptr;
+  // scene
+  std::vector<unsigned char> hostBlob;
+  unsigned char *dBlob = nullptr;
+  std::vector<void *> sceneAllocs;  // derived arrays
+  DScene ds{};
+  bool haveScene = false;
+  float *dHalton = nullptr;
+  int haltonCount = 0;
+  // launch plumbing
+  static const int kCounterRing = 64;
+  unsigned int *dWork = nullptr;  // ring of work counters
+  int workNext = 0;
+  int *hStop = nullptr;           // mapped host memory, read by the kernel's wave leaders
+  int *dStopAlias = nullptr;
+  DCounters *dCounters = nullptr;
+  // host-variant staging
+  float *dRgb = nullptr, *dDepth = nullptr;
+  uint32_t *dNs = nullptr;
+  size_t stagePixels = 0;
+  // timing
+  std::vector<EventPair> pending, freeEvents;
+  double totalMs = 0;
+  uint64_t launches = 0;
+  int blocksPerCU = 4, threads = QA_BLOCK;
+};
+
+static void FreeScene(qa_ctx *c)
+{
+  for (void *p : c->sceneAllocs) (void) hipFree(p);
+  c->sceneAllocs.clear();
+  if (c->dBlob) (void) hipFree(c->dBlob);
+  c->dBlob = nullptr;
+  c->haveScene = false;
+}
+
+template <class T>
+static int DeviceCopy(qa_ctx *c, const std::vector<T> &v, const T **out)
+{
+  *out = nullptr;
+  if (v.empty()) return QA_OK;
+  void *p = nullptr;
+  HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+  c->sceneAllocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T *>(p);
+  return QA_OK;
+}
+
+// core/sampler.cpp:31-40, evaluated on the host in the reference's fp32 order
+static float HaltonF(int index, int base)
+{
+  float r = 0;
+  float f = 1.0f / (float) base;
+  for (int i = index; i > 0; i /= base) {
+    r += f * (i % base);
+    f /= (float) base;
+  }
+  return r;
+}
+
+static int EnsureHalton(qa_ctx *c, int count)
+{
+  if (count <= c->haltonCount) return QA_OK;
+  int n = 64;
+  while (n < count) n *= 2;
+  std::vector<float> t(2 * (size_t) n);
+  for (int s = 0; s < n; ++s) { t[2 * s] = HaltonF(s, 11); t[2 * s + 1] = HaltonF(s, 13); }
+  if (c->dHalton) (void) hipFree(c->dHalton);
+  c->dHalton = nullptr;
+  HIP_TRY(hipMalloc((void **) &c->dHalton, t.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(c->dHalton, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->haltonCount = n;
+  return QA_OK;
+}
+
+// Validate the blob and build the device tables.
+static int PrepareScene(qa_ctx *c)
+{
+  const unsigned char *blob = c->hostBlob.data();
+  const size_t nbytes = c->hostBlob.size();
+  if (nbytes < sizeof(qa_flat_header)) return Fail(QA_EINVAL, "blob smaller than its header");
+  const qa_flat_header *h = reinterpret_cast<const qa_flat_header *>(blob);
+  if (h->magic != QA_FLAT_MAGIC || h->version != QA_FLAT_VERSION) return Fail(QA_EINVAL, "not a qaray flat scene (magic/version)");
+  if (h->total_bytes != nbytes) return Fail(QA_EINVAL, "blob size does not match its header");
+  auto inside = [&](uint64_t off, uint64_t bytes) { return off <= nbytes && bytes <= nbytes - off; };
+  if (!inside(h->off_instances, (uint64_t) h->num_instances * sizeof(qa_instance)) ||
+      !inside(h->off_meshes, (uint64_t) h->num_meshes * sizeof(qa_mesh)) ||
+      !inside(h->off_mtlsets, (uint64_t) h->num_mtlsets * sizeof(qa_mtlset)) ||
+      !inside(h->off_materials, (uint64_t) h->num_materials * sizeof(qa_material)) ||
+      !inside(h->off_lights, (uint64_t) h->num_lights * sizeof(qa_light)) ||
+      !inside(h->off_texmaps, (uint64_t) h->num_texmaps * sizeof(qa_texmap)) ||
+      !inside(h->off_textures, (uint64_t) h->num_textures * sizeof(qa_texture)))
+    return Fail(QA_EINVAL, "table outside the blob");
+  if (h->num_instances == 0 || h->width == 0 || h->height == 0) return Fail(QA_EINVAL, "empty scene");
+
+  const qa_instance *inst = QA_BLOB_PTR(qa_instance, blob, h->off_instances);
+  const qa_mesh *mesh = QA_BLOB_PTR(qa_mesh, blob, h->off_meshes);
+  const qa_mtlset *mtlset = QA_BLOB_PTR(qa_mtlset, blob, h->off_mtlsets);
+  const qa_light *light = QA_BLOB_PTR(qa_light, blob, h->off_lights);
+  for (uint32_t k = 0; k < h->num_instances; ++k) {
+    const qa_instance &in = inst[k];
+    if (in.depth > QA_MAX_NODE_DEPTH) return Fail(QA_EUNSUPPORTED, "node nesting deeper than QA_MAX_NODE_DEPTH");
+    if (in.parent >= (int) k || (k > 0 && in.parent < 0)) return Fail(QA_EINVAL, "instances are not in pre-order");
+    if (in.obj_type == QA_OBJ_MESH && (in.mesh < 0 || in.mesh >= (int) h->num_meshes)) return Fail(QA_EINVAL, "bad mesh index");
+    if (in.mtlset >= (int) h->num_mtlsets) return Fail(QA_EINVAL, "bad material index");
+  }
+  for (uint32_t i = 0; i < h->num_mtlsets; ++i)
+    if (mtlset[i].first < 0 || mtlset[i].count < 0 || (uint32_t) (mtlset[i].first + mtlset[i].count) > h->num_materials)
+      return Fail(QA_EINVAL, "bad material range");
+  for (uint32_t i = 0; i < h->num_lights; ++i)
+    if ((light[i].type == QA_LIGHT_POINT || light[i].type == QA_LIGHT_SPOT) && light[i].size > 0.01f)
+      return Fail(QA_EUNSUPPORTED, "area lights (size > 0.01) need post-order RNG replay: not implemented on the HIP path yet");
+  if (h->num_texmaps > 0)
+    return Fail(QA_EUNSUPPORTED, "textured colours are not implemented on the HIP path yet");
+
+  // ---- derived per-mesh arrays --------------------------------------------------------------
+  std::vector<DMesh> dmeshes(h->num_meshes);
+  for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
+    const qa_mesh &m = mesh[mi];
+    if (!inside(m.off_bvh_nodes, (uint64_t) m.num_bvh_nodes * sizeof(qa_bvh_node)) ||
+        !inside(m.off_elements, (uint64_t) m.num_faces * 4) || !inside(m.off_faces, (uint64_t) m.num_faces * sizeof(qa_face)) ||
+        !inside(m.off_vertices, (uint64_t) m.num_vertices * 12) || !inside(m.off_normals, (uint64_t) m.num_normals * 12) ||
+        !inside(m.off_texcoords, (uint64_t) m.num_texcoords * 8))
+      return Fail(QA_EINVAL, "mesh array outside the blob");
+    const qa_bvh_node *nodes = QA_BLOB_PTR(qa_bvh_node, blob, m.off_bvh_nodes);
+    const uint32_t *elements = QA_BLOB_PTR(uint32_t, blob, m.off_elements);
+    const qa_face *faces = QA_BLOB_PTR(qa_face, blob, m.off_faces);
+    const float *V = QA_BLOB_PTR(float, blob, m.off_vertices);
+    const float *VN = QA_BLOB_PTR(float, blob, m.off_normals);
+    const float *VT = QA_BLOB_PTR(float, blob, m.off_texcoords);
+    std::vector<DNode> dn(m.num_bvh_nodes);
+    for (uint32_t i = 0; i < m.num_bvh_nodes; ++i) {
+      memcpy(dn[i].box, nodes[i].box, sizeof(dn[i].box));
+      dn[i].data = nodes[i].data;
+      dn[i].pad = 0;
+      if (i >= 1 && !(nodes[i].data & QA_BVH_LEAF_BIT) && m.num_faces > 0) {
+        const uint32_t c = nodes[i].data & QA_BVH_CHILD_MASK;
+        if (c + 1 >= m.num_bvh_nodes) return Fail(QA_EINVAL, "BVH child index out of range");
+      } else if (i >= 1 && m.num_faces > 0) {
+        const uint32_t cnt = ((nodes[i].data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+        if ((nodes[i].data & QA_BVH_OFFSET_MASK) + cnt > m.num_faces) return Fail(QA_EINVAL, "BVH leaf range out of range");
+      }
+    }
+    std::vector<DTri> dt(m.num_faces);
+    std::vector<DTriShade> dsh(m.num_faces);
+    for (uint32_t e = 0; e < m.num_faces; ++e) {
+      const uint32_t fid = elements[e];
+      if (fid >= m.num_faces) return Fail(QA_EINVAL, "BVH element out of range");
+      const qa_face &f = faces[fid];
+      for (int k = 0; k < 3; ++k) {
+        if (f.v[k] < 0 || (uint32_t) f.v[k] >= m.num_vertices) return Fail(QA_EINVAL, "vertex index out of range");
+        if (f.vn[k] < 0 || (uint32_t) f.vn[k] >= m.num_normals) return Fail(QA_EINVAL, "normal index out of range");
+      }
+      const f3 A = ld3(V + 3 * f.v[0]), B = ld3(V + 3 * f.v[1]), C = ld3(V + 3 * f.v[2]);
+      // src/objects/objects.cpp:220-246
+      const f3 N = normalize(cross(B - A, C - A));
+      uint32_t axis;
+      const float ax = qabs(N.x), ay = qabs(N.y), az = qabs(N.z);
+      if (ax > ay && ax > az) axis = 0;
+      else if (ay > az) axis = 1;
+      else axis = 2;
+      auto U = [&](f3 p) { return axis == 0 ? p.y : p.x; };
+      auto W = [&](f3 p) { return axis == 2 ? p.y : p.z; };
+      DTri &t = dt[e];
+      t.N[0] = N.x; t.N[1] = N.y; t.N[2] = N.z;
+      t.A[0] = A.x; t.A[1] = A.y; t.A[2] = A.z;
+      t.au = U(A); t.av = W(A); t.bu = U(B); t.bv = W(B); t.cu = U(C); t.cv = W(C);
+      // TriangleArea(axis, A, B, C) (objects.cpp:30-41)
+      const float area = (t.bu - t.au) * (t.cv - t.av) - (t.cu - t.au) * (t.bv - t.av);
+      t.s = 1.f / area;
+      t.axis = axis;
+      t.face = fid;
+      t.pad = 0;
+      DTriShade &s = dsh[e];
+      memcpy(s.n0, VN + 3 * f.vn[0], 12);
+      memcpy(s.n1, VN + 3 * f.vn[1], 12);
+      memcpy(s.n2, VN + 3 * f.vn[2], 12);
+      s.hasVT = (f.vt[0] >= 0 && f.vt[1] >= 0 && f.vt[2] >= 0) ? 1 : 0;
+      memset(s.t0, 0, 24);
+      if (s.hasVT) {
+        for (int k = 0; k < 3; ++k) if ((uint32_t) f.vt[k] >= m.num_texcoords) return Fail(QA_EINVAL, "texcoord index out of range");
+        memcpy(s.t0, VT + 2 * f.vt[0], 8);
+        memcpy(s.t1, VT + 2 * f.vt[1], 8);
+        memcpy(s.t2, VT + 2 * f.vt[2], 8);
+      }
+      s.mtl = f.mtl;
+    }
+    DMesh &dm = dmeshes[mi];
+    memcpy(dm.bmin, m.bmin, 12);
+    memcpy(dm.bmax, m.bmax, 12);
+    dm.num_faces = m.num_faces;
+    dm.num_nodes = m.num_bvh_nodes;
+    dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : 0;
+    dm.pad = 0;
+    int rc;
+    if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, dt, &dm.tris)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, dsh, &dm.shade)) != QA_OK) return rc;
+  }
+
+  DScene &ds = c->ds;
+  memset(&ds, 0, sizeof(ds));
+  ds.blob = c->dBlob;
+  ds.inst = QA_BLOB_PTR(qa_instance, c->dBlob, h->off_instances);
+  ds.mtlset = QA_BLOB_PTR(qa_mtlset, c->dBlob, h->off_mtlsets);
+  ds.mtl = QA_BLOB_PTR(qa_material, c->dBlob, h->off_materials);
+  ds.light = QA_BLOB_PTR(qa_light, c->dBlob, h->off_lights);
+  ds.texmap = QA_BLOB_PTR(qa_texmap, c->dBlob, h->off_texmaps);
+  ds.tex = QA_BLOB_PTR(qa_texture, c->dBlob, h->off_textures);
+  int rc;
+  if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
+  memcpy(ds.cam.screenA, h->screenA, 12);
+  memcpy(ds.cam.screenU, h->screenU, 12);
+  memcpy(ds.cam.screenV, h->screenV, 12);
+  memcpy(ds.cam.screenX, h->screenX, 12);
+  memcpy(ds.cam.screenY, h->screenY, 12);
+  memcpy(ds.cam.pos, h->cam_pos, 12);
+  ds.cam.dof = h->dof;
+  ds.cam.width = (int) h->width;
+  ds.cam.height = (int) h->height;
+  ds.background = h->background;
+  ds.environment = h->environment;
+  ds.num_inst = (int) h->num_instances;
+  ds.num_lights = (int) h->num_lights;
+  c->haveScene = true;
+  return QA_OK;
+}
+
+template <bool STATS>
+static void Launch(qa_ctx *c, const RenderParams &rp, int blocks, hipStream_t s)
+{
+  hipLaunchKernelGGL(qa_integrate<STATS>, dim3((unsigned) blocks), dim3(QA_BLOCK), 0, s, c->ds, rp);
+}
+
+static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int spp_max, int max_bounce,
+                  uint32_t seed, uint32_t flags, float *d_rgb, float *d_depth, uint32_t *d_ns, hipStream_t s)
+{
+  if (!c->haveScene) return Fail(QA_ENOSCENE, "no scene uploaded");
+  if (x0 < 0 || y0 < 0 || x1 > c->ds.cam.width || y1 > c->ds.cam.height || x1 <= x0 || y1 <= y0)
+    return Fail(QA_EINVAL, "region outside the image");
+  if (spp_min < 0 || spp_max < spp_min || spp_max < 1 || max_bounce < 0) return Fail(QA_EINVAL, "bad spp / bounce");
+  if (!d_rgb || !d_depth || !d_ns) return Fail(QA_EINVAL, "null output buffer");
+  int rc = EnsureHalton(c, spp_max);
+  if (rc != QA_OK) return rc;
+  c->ds.halton = c->dHalton;
+  c->ds.halton_count = c->haltonCount;
+
+  const size_t npix = (size_t) (x1 - x0) * (y1 - y0);
+  // pixels skipped by a stop request must read as "not rendered"
+  HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
+  unsigned int *work = c->dWork + c->workNext;
+  c->workNext = (c->workNext + 1) % qa_ctx::kCounterRing;
+  HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
+
+  RenderParams rp;
+  rp.x0 = x0; rp.y0 = y0; rp.x1 = x1; rp.y1 = y1;
+  rp.spp_min = spp_min; rp.spp_max = spp_max; rp.max_bounce = max_bounce;
+  rp.seed = seed;
+  rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
+  rp.work_counter = work;
+  rp.stop_flag = c->dStopAlias;
+  rp.counters = c->dCounters;
+
+  const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ((y1 - y0 + 7) / 8);
+  const long long needBlocks = ((long long) tiles * 64 + QA_BLOCK - 1) / QA_BLOCK;
+  long long blocks = (long long) c->numCUs * c->blocksPerCU;
+  if (blocks > needBlocks) blocks = needBlocks;
+  if (blocks < 1) blocks = 1;
+
+  EventPair ev;
+  if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
+  else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+  HIP_TRY(hipEventRecord(ev.a, s));
+  if (flags & QA_RENDER_STATS) Launch<true>(c, rp, (int) blocks, s);
+  else Launch<false>(c, rp, (int) blocks, s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.b, s));
+  c->pending.push_back(ev);
+  c->launches++;
+  return QA_OK;
+}
+
+static int DrainEvents(qa_ctx *c)
+{
+  for (EventPair &ev : c->pending) {
+    HIP_TRY(hipEventSynchronize(ev.b));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    c->totalMs += ms;
+    c->freeEvents.push_back(ev);
+  }
+  c->pending.clear();
+  return QA_OK;
+}
+
+extern "C" {
+
+const char *qa_last_error(void) { return g_err.c_str(); }
+
+int qa_ctx_create(int device_id, qa_ctx **out)
+{
+  if (!out) return Fail(QA_EINVAL, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return Fail(QA_EHIP, "no HIP device: the qaray HIP path has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return Fail(QA_EINVAL, "device id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  qa_ctx *c = new (std::nothrow) qa_ctx;
+  if (!c) return Fail(QA_ENOMEM, "out of memory");
+  c->device = device_id;
+  c->numCUs = prop.multiProcessorCount;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc((void **) &c->dWork, qa_ctx::kCounterRing * sizeof(unsigned int))) != hipSuccess ||
+      (e = hipMalloc((void **) &c->dCounters, sizeof(DCounters))) != hipSuccess ||
+      (e = hipMemset(c->dCounters, 0, sizeof(DCounters))) != hipSuccess ||
+      (e = hipHostMalloc((void **) &c->hStop, sizeof(int), hipHostMallocMapped)) != hipSuccess) {
+    qa_ctx_destroy(c);
+    return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
+  }
+  *c->hStop = 0;
+  if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
+    qa_ctx_destroy(c);
+    return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return QA_OK;
+}
+
+int qa_ctx_destroy(qa_ctx *c)
+{
+  if (!c) return QA_OK;
+  (void) hipSetDevice(c->device);
+  if (c->stream) (void) hipStreamSynchronize(c->stream);
+  FreeScene(c);
+  for (EventPair &ev : c->pending) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
+  for (EventPair &ev : c->freeEvents) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
+  if (c->dHalton) (void) hipFree(c->dHalton);
+  if (c->dWork) (void) hipFree(c->dWork);
+  if (c->dCounters) (void) hipFree(c->dCounters);
+  if (c->hStop) (void) hipHostFree(c->hStop);
+  if (c->dRgb) (void) hipFree(c->dRgb);
+  if (c->dDepth) (void) hipFree(c->dDepth);
+  if (c->dNs) (void) hipFree(c->dNs);
+  if (c->stream) (void) hipStreamDestroy(c->stream);
+  delete c;
+  return QA_OK;
+}
+
+int qa_scene_upload(qa_ctx *c, const void *host_blob, uint64_t nbytes)
+{
+  if (!c || !host_blob || nbytes == 0) return Fail(QA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  FreeScene(c);
+  try {
+    c->hostBlob.assign((const unsigned char *) host_blob, (const unsigned char *) host_blob + nbytes);
+  } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+  HIP_TRY(hipMalloc((void **) &c->dBlob, nbytes));
+  HIP_TRY(hipMemcpy(c->dBlob, host_blob, nbytes, hipMemcpyHostToDevice));
+  const int rc = PrepareScene(c);
+  if (rc != QA_OK) FreeScene(c);
+  return rc;
+}
+
+int qa_scene_upload_device(qa_ctx *c, const void *device_blob, uint64_t nbytes)
+{
+  if (!c || !device_blob || nbytes == 0) return Fail(QA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  FreeScene(c);
+  try { c->hostBlob.resize(nbytes); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+  HIP_TRY(hipMalloc((void **) &c->dBlob, nbytes));
+  HIP_TRY(hipMemcpy(c->dBlob, device_blob, nbytes, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipMemcpy(c->hostBlob.data(), device_blob, nbytes, hipMemcpyDeviceToHost));
+  const int rc = PrepareScene(c);
+  if (rc != QA_OK) FreeScene(c);
+  return rc;
+}
+
+int qa_render_region_device(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int spp_max, int max_bounce,
+                            uint32_t seed, uint32_t flags, float *d_rgb, float *d_depth, uint32_t *d_ns, void *hip_stream)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  return Render(c, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
+}
+
+int qa_render_region(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int spp_max, int max_bounce,
+                     uint32_t seed, uint32_t flags, float *rgb, float *depth, uint32_t *ns)
+{
+  if (!c || !rgb || !depth || !ns) return Fail(QA_EINVAL, "null argument");
+  if (x1 <= x0 || y1 <= y0) return Fail(QA_EINVAL, "empty region");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t npix = (size_t) (x1 - x0) * (y1 - y0);
+  if (npix > c->stagePixels) {
+    if (c->dRgb) (void) hipFree(c->dRgb);
+    if (c->dDepth) (void) hipFree(c->dDepth);
+    if (c->dNs) (void) hipFree(c->dNs);
+    c->dRgb = c->dDepth = nullptr;
+    c->dNs = nullptr;
+    c->stagePixels = 0;
+    HIP_TRY(hipMalloc((void **) &c->dRgb, npix * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **) &c->dDepth, npix * sizeof(float)));
+    HIP_TRY(hipMalloc((void **) &c->dNs, npix * sizeof(uint32_t)));
+    c->stagePixels = npix;
+  }
+  const int rc = Render(c, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed, flags, c->dRgb, c->dDepth, c->dNs, c->stream);
+  if (rc != QA_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(rgb, c->dRgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(depth, c->dDepth, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(ns, c->dNs, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QA_OK;
+}
+
+int qa_synchronize(qa_ctx *c)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DrainEvents(c);
+}
+
+int qa_request_stop(qa_ctx *c)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  __atomic_store_n(c->hStop, 1, __ATOMIC_SEQ_CST);
+  return QA_OK;
+}
+int qa_clear_stop(qa_ctx *c)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  __atomic_store_n(c->hStop, 0, __ATOMIC_SEQ_CST);
+  return QA_OK;
+}
+
+int qa_get_counters(qa_ctx *c, qa_counters *out)
+{
+  if (!c || !out) return Fail(QA_EINVAL, "null argument");
+  int rc = qa_synchronize(c);
+  if (rc != QA_OK) return rc;
+  DCounters h;
+  HIP_TRY(hipMemcpy(&h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
+  out->samples = h.samples;
+  out->casts_normal = h.casts_normal;
+  out->casts_shadow = h.casts_shadow;
+  out->bvh_nodes = h.bvh_nodes;
+  out->tri_tests = h.tri_tests;
+  out->pixels = h.pixels;
+  return QA_OK;
+}
+int qa_reset_counters(qa_ctx *c)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  int rc = qa_synchronize(c);
+  if (rc != QA_OK) return rc;
+  HIP_TRY(hipMemset(c->dCounters, 0, sizeof(DCounters)));
+  return QA_OK;
+}
+
+int qa_get_kernel_time(qa_ctx *c, double *total_ms, uint64_t *launches)
+{
+  if (!c || !total_ms || !launches) return Fail(QA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = DrainEvents(c);
+  if (rc != QA_OK) return rc;
+  *total_ms = c->totalMs;
+  *launches = c->launches;
+  return QA_OK;
+}
+int qa_reset_kernel_time(qa_ctx *c)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = DrainEvents(c);
+  if (rc != QA_OK) return rc;
+  c->totalMs = 0;
+  c->launches = 0;
+  return QA_OK;
+}
+
+int qa_set_launch_config(qa_ctx *c, int blocks_per_cu, int threads_per_block)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  if (threads_per_block != 0 && threads_per_block != QA_BLOCK) return Fail(QA_EINVAL, "this build supports 256-thread workgroups only");
+  if (blocks_per_cu < 0 || blocks_per_cu > 8) return Fail(QA_EINVAL, "blocks_per_cu must be in 0..8");
+  c->blocksPerCU = blocks_per_cu == 0 ? 4 : blocks_per_cu;
+  return QA_OK;
+}
+
+}  // extern "C"

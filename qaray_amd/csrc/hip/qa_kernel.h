@@ -1,0 +1,684 @@
+// qa_kernel.h — the integrator: one persistent HIP kernel that runs qaray's whole per-pixel
+// Monte-Carlo loop on gfx950.
+//
+// What it replaces (reference file:line): Renderer::ThreadRender/PixelRender
+// (src/renderers/renderer.cpp:302-423), SuperSamplerHalton (src/scene/scene.cpp:83-123),
+// Scene::TraceNodeNormal/TraceNodeShadow (src/scene/scene.cpp:35-74), Sphere/Plane/TriObj
+// intersectors and the BVH walk (src/objects/objects.cpp:55-420), MtlBlinn_PhotonMap::Shade with
+// MultiMtl dispatch (src/materials/MtlBlinn_PhotonMap.cpp:65-500, materials.h:70-76), the lights
+// (src/lights/lights.cpp:39-144) and the xorshift32 sampler (src/samplers/Sampler_Marsaglia.cpp).
+//
+// Execution model (MI355X-first, not a translation of the CPU recursion):
+//  * Persistent threads.  The grid is sized to the chip (blocks_per_cu x 256 CUs); every LANE owns
+//    one pixel at a time and runs a small state machine: [fetch pixel] -> [start sample: camera
+//    ray] -> trace -> shade -> (next bounce | sample finished).  A finished path is replaced in
+//    the same loop iteration by the pixel's next sample, a finished pixel by a new pixel pulled
+//    from a global work counter with ONE atomic per wavefront (ballot + mbcnt prefix), so all 64
+//    lanes of a wave trace a ray in every iteration and no ray/hit queue ever goes through HBM:
+//    path state lives in VGPRs, the BVH stack in LDS.
+//  * The reference's recursion (Shade -> TraceNodeNormal -> Shade ...) is a chain, because
+//    exactly one of reflect / transmit / diffuse is followed per hit; it is unrolled into an
+//    iteration that carries a throughput.  Random numbers are drawn in the reference's order
+//    (select, lobe sample, then the deeper hits); lights that draw random numbers (area lights)
+//    are rejected at upload time because they would need a post-order replay.
+//  * One xorshift32 stream per pixel (include/qa_seed.h); a pixel's samples are sequential by
+//    construction, pixels are the parallel dimension.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "qa_device_math.h"
+#include "qa_scene_dev.h"
+#include "qa_seed.h"
+
+namespace qa {
+
+#define QA_BLOCK 256
+#define QA_STACK 32            /* LDS entries per lane; the reference uses 40 (src/objects/objects.cpp:331) */
+#define QA_BIAS 0.005f         /* src/objects/objects.cpp:19 */
+#define QA_DX 0.01f            /* DiffRay::dx, src/core/ray.cpp:31 */
+
+struct Ray { f3 p, d; };
+
+struct Hit {
+  float z;      // world-parametric distance (rays are not renormalised in node space)
+  f3 p, N;      // node-local until finishHit() maps them to world space
+  int node;     // instance index, -1 = none
+  int mtlID;
+  bool front;
+};
+
+// ---------------------------------------------------------------------------------------------
+// RNG: Sampler_Marsaglia::xorshift32 (src/samplers/Sampler_Marsaglia.cpp:43-53)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rng1(uint32_t &state)
+{
+  uint32_t x = state;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  state = x;
+  return (float) x / 4294967296.0f;
+}
+
+// Sampler::UniformBall (src/core/sampler.cpp:42-53); z uses r2 like the reference
+__device__ __forceinline__ f3 uniformBall(uint32_t &rng, float radius)
+{
+  f3 p;
+  do {
+    const float r1 = rng1(rng), r2 = rng1(rng);
+    (void) rng1(rng);
+    p.x = (2.f * r1 - 1.f) * radius;
+    p.y = (2.f * r2 - 1.f) * radius;
+    p.z = (2.f * r2 - 1.f) * radius;
+  } while (length(p) > radius);
+  return p;
+}
+
+// TransformToLocalFrame (src/math/math.cpp:37-46)
+__device__ __forceinline__ f3 toLocalFrame(f3 N, f3 sample)
+{
+  const f3 Z = N;
+  const f3 Y = (qabs(Z.x) > qabs(Z.y)) ? normalize(F3(Z.z, 0, -Z.x)) : normalize(F3(0, -Z.z, Z.y));
+  const f3 X = normalize(cross(Y, Z));
+  const f3 unit = normalize(sample);
+  return (X * unit.x + Y * unit.y) + Z * unit.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node transforms (src/core/node.cpp:112-139, src/core/transform.h:47-61)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Ray toNode(const qa_instance &in, const Ray &r)
+{
+  const f3 pos = ld3(in.pos);
+  Ray o;
+  o.p = mulMV(in.itm, r.p - pos);
+  o.d = mulMV(in.itm, (r.p + r.d) - pos) - o.p;
+  return o;
+}
+
+// Local ray of instance k: the root's transform has already been applied (r0); walk the rest of
+// the ancestor chain top-down.  All lanes work on the same k, so the chain is wave-uniform.
+__device__ __forceinline__ Ray localRay(const DScene &sc, int k, const Ray &r0)
+{
+  int chain[QA_MAX_NODE_DEPTH];
+  int n = 0;
+  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = sc.inst[a].parent) chain[n++] = a;
+  Ray r = r0;
+  for (int q = n - 1; q >= 0; --q) r = toNode(sc.inst[chain[q]], r);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intersectors.  `closest` = false is a shadow query (diffray == NULL in the reference): only
+// h.z is maintained and the caller stops at the first hit.
+// ---------------------------------------------------------------------------------------------
+// Sphere::IntersectRay (src/objects/objects.cpp:55-141)
+__device__ __forceinline__ bool hitSphere(const Ray &ray, Hit &h, int k, bool closest)
+{
+  const float a = dot(ray.d, ray.d);
+  const float b = 2.f * dot(ray.p, ray.d);
+  const float c = dot(ray.p, ray.p) - 1;
+  const float rcp2a = 1.f / (2.f * a);
+  const float delta = b * b - 4 * a * c;
+  float t = QA_BIGFLOAT;
+  if (delta < 0) return false;
+  if (delta == 0) {
+    const float t0 = -b * rcp2a;
+    if (t0 <= QA_BIAS) return false;
+    t = t0;
+  } else {
+    const float sq = qsqrt(delta);
+    const float t1 = (-b - sq) * rcp2a;
+    const float t2 = (-b + sq) * rcp2a;
+    if (t1 <= QA_BIAS && t2 <= QA_BIAS) return false;
+    else if (t1 > QA_BIAS) t = qmin(t, t1);
+    else if (t2 > QA_BIAS) t = qmin(t, t2);
+  }
+  if (h.z > t) {
+    h.z = t;
+    if (closest) {
+      const f3 p = ray.p + ray.d * t;
+      const f3 N = normalize(p);
+      h.p = p;
+      h.N = N;
+      h.front = (dot(N, ray.d) <= 0);
+      h.node = k;
+    }
+    return true;
+  }
+  return false;
+}
+
+// Plane::IntersectRay (src/objects/objects.cpp:149-208)
+__device__ __forceinline__ bool hitPlane(const Ray &ray, Hit &h, int k, bool closest)
+{
+  const f3 N = F3(0, 0, 1);
+  const float dz = dot(ray.d, N);
+  if (qabs(dz) < 1e-7f) return false;
+  const float pz = dot(ray.p, N);
+  const float t = -pz / dz;
+  if (t <= QA_BIAS) return false;
+  if (h.z > t) {
+    const f3 p = ray.p + ray.d * t;
+    if (qabs(p.x) > 1.f || qabs(p.y) > 1.f) return false;
+    h.z = t;
+    if (closest) {
+      h.p = p;
+      h.N = N;
+      h.front = (dot(N, ray.d) <= 0);
+      h.node = k;
+    }
+    return true;
+  }
+  return false;
+}
+
+// One axis of the slab test (src/objects/objects.cpp:360-395, src/core/box.cpp:103-123)
+__device__ __forceinline__ void slab(float d, float p0, float p1, float &t0, float &t1)
+{
+  if (qabs(d) < 1e-7f) { t0 = -QA_BIGFLOAT; t1 = QA_BIGFLOAT; }
+  else { t0 = qmin(p0, p1); t1 = qmax(p0, p1); }
+}
+__device__ __forceinline__ void boxEntryExit(const Ray &ray, f3 drcp, const float *box, float &entry, float &exit_)
+{
+  const f3 p0 = (-(ray.p - ld3(box))) * drcp;
+  const f3 p1 = (-(ray.p - ld3(box + 3))) * drcp;
+  f3 t0, t1;
+  slab(ray.d.x, p0.x, p1.x, t0.x, t1.x);
+  slab(ray.d.y, p0.y, p1.y, t0.y, t1.y);
+  slab(ray.d.z, p0.z, p1.z, t0.z, t1.z);
+  entry = qmax(t0.x, qmax(t0.y, t0.z));
+  exit_ = qmin(t1.x, qmin(t1.y, t1.z));
+}
+
+// TriObj::IntersectTriangle (src/objects/objects.cpp:212-306) on a precomputed record.
+// TriangleArea(axis, P, Q, R) = (Q.u-P.u)*(R.v-P.v) - (R.u-P.u)*(Q.v-P.v) with (u,v) the two
+// coordinates kept after dropping `axis` (objects.cpp:30-41).
+template <bool STATS>
+__device__ __forceinline__ bool hitTriangle(const DTri &tr, const Ray &ray, Hit &h, float &ba, float &bb,
+                                            DCounters &cnt)
+{
+  if (STATS) cnt.tri_tests++;
+  const f3 N = ld3(tr.N);
+  const float dz = dot(ray.d, N);
+  if (qabs(dz) < 1e-7f) return false;
+  const float pz = dot(ray.p - ld3(tr.A), N);
+  const float t = -pz / dz;
+  if (t <= QA_BIAS) return false;
+  if (h.z > t) {
+    const f3 p = ray.p + ray.d * t;
+    const float pu = (tr.axis == 0) ? p.y : p.x;
+    const float pv = (tr.axis == 2) ? p.y : p.z;
+    const float a = ((tr.bu - pu) * (tr.cv - pv) - (tr.cu - pu) * (tr.bv - pv)) * tr.s;
+    const float b = ((tr.cu - pu) * (tr.av - pv) - (tr.au - pu) * (tr.cv - pv)) * tr.s;
+    const float c = 1.f - a - b;
+    if (a < 0 || b < 0 || c < 0) return false;
+    h.z = t;
+    h.p = p;
+    h.front = (dz <= 0);
+    ba = a;
+    bb = b;
+    return true;
+  }
+  return false;
+}
+
+// TriObj::IntersectRay + TraceBVHNode (src/objects/objects.cpp:310-420).  The traversal stack
+// holds the popped node's DATA word (leaf flag + range, or child index) instead of its id: the
+// word arrives together with the node's box when the parent tests its two children, so an inner
+// visit costs a single 64-byte read of the sibling pair.
+template <bool STATS>
+__device__ __forceinline__ bool hitMesh(const DMesh &m, const Ray &ray, Hit &h, int k, bool closest,
+                                        uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt)
+{
+  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  {
+    float box[6] = {m.bmin[0], m.bmin[1], m.bmin[2], m.bmax[0], m.bmax[1], m.bmax[2]};
+    float entry, exit_;
+    boxEntryExit(ray, drcp, box, entry, exit_);
+    if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
+  }
+  if (m.num_faces == 0) return false;
+  bool hasHit = false;
+  int sp = 0;
+  uint32_t bestTri = 0;
+  float ba = 0, bb = 0;
+  stack[0] = m.rootData;
+  sp = 1;
+  while (sp != 0) {
+    const uint32_t data = stack[(--sp) * QA_BLOCK];
+    if (STATS) cnt.bvh_nodes++;
+    if (data & QA_BVH_LEAF_BIT) {
+      const uint32_t count = ((data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+      const uint32_t first = data & QA_BVH_OFFSET_MASK;
+      for (uint32_t i = 0; i < count; ++i) {
+        if (hitTriangle<STATS>(m.tris[first + i], ray, h, ba, bb, cnt)) {
+          hasHit = true;
+          bestTri = first + i;
+          if (!closest) return true;
+        }
+      }
+    } else {
+      const uint32_t c0 = data & QA_BVH_CHILD_MASK;
+      const DNode &n0 = m.nodes[c0];
+      const DNode &n1 = m.nodes[c0 + 1];
+      float entry0, exit0, entry1, exit1;
+      boxEntryExit(ray, drcp, n0.box, entry0, exit0);
+      boxEntryExit(ray, drcp, n1.box, entry1, exit1);
+      const float t_max = h.z;
+      const bool hit0 = (entry0 < t_max && entry0 < exit0);
+      const bool hit1 = (entry1 < t_max && entry1 < exit1);
+      if (hit0 && hit1) {
+        const bool nearFirst = entry0 < entry1;
+        stack[(sp++) * QA_BLOCK] = nearFirst ? n1.data : n0.data;
+        stack[(sp++) * QA_BLOCK] = nearFirst ? n0.data : n1.data;
+      } else if (hit0) stack[(sp++) * QA_BLOCK] = n0.data;
+      else if (hit1) stack[(sp++) * QA_BLOCK] = n1.data;
+      if (sp > QA_STACK - 2) break;  // deeper than the reference's own stack allows
+    }
+  }
+  if (hasHit && closest) {
+    // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
+    const DTriShade &s = m.shade[bestTri];
+    const float bc = 1.f - ba - bb;
+    h.N = (ld3(s.n0) * ba + ld3(s.n1) * bb) + ld3(s.n2) * bc;
+    h.mtlID = s.mtl;
+    h.node = k;
+  }
+  return hasHit;
+}
+
+// Scene::TraceNodeNormal (src/scene/scene.cpp:50-74): closest hit over every node in pre-order.
+template <bool STATS>
+__device__ __forceinline__ bool traceClosest(const DScene &sc, const Ray &world, Hit &h, uint32_t *stack,
+                                             DCounters &cnt)
+{
+  cnt.casts_normal++;
+  const Ray r0 = toNode(sc.inst[0], world);
+  bool any = false;
+  for (int k = 1; k < sc.num_inst; ++k) {
+    const int type = sc.inst[k].obj_type;
+    if (type == QA_OBJ_NONE) continue;
+    const Ray r = localRay(sc, k, r0);
+    bool hit;
+    if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, true);
+    else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, true);
+    else hit = hitMesh<STATS>(sc.mesh[sc.inst[k].mesh], r, h, k, true, stack, cnt);
+    any |= hit;
+  }
+  if (any) {
+    // Node::FromNodeCoords at every level from the hit node up to and including the root
+    // (src/core/node.cpp:127-139); the reference applies them as its recursion unwinds.
+    for (int a = h.node; a >= 0; a = sc.inst[a].parent) {
+      const qa_instance &in = sc.inst[a];
+      h.p = mulMV(in.tm, h.p) + ld3(in.pos);
+      h.N = normalize(mulTMV(in.itm, h.N));
+    }
+  }
+  return any;
+}
+
+// GenLight::Shadow -> Scene::TraceNodeShadow (src/lights/lights.cpp:39-48, src/scene/scene.cpp:35-46)
+template <bool STATS>
+__device__ __forceinline__ float shadow(const DScene &sc, const Ray &world, float t_max, uint32_t *stack,
+                                        DCounters &cnt)
+{
+  cnt.casts_shadow++;
+  Hit h;
+  h.z = t_max;
+  h.node = -1;
+  const Ray r0 = toNode(sc.inst[0], world);
+  for (int k = 1; k < sc.num_inst; ++k) {
+    const int type = sc.inst[k].obj_type;
+    if (type == QA_OBJ_NONE) continue;
+    const Ray r = localRay(sc, k, r0);
+    bool hit;
+    if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
+    else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
+    else hit = hitMesh<STATS>(sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt);
+    if (hit) return 0.0f;
+  }
+  return 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lights (src/lights/lights.h:35-171, src/lights/lights.cpp:23-144); area lights (size > 0.01)
+// are rejected at upload.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float inverseSquareFalloff(f3 v) { return qmin(1.f, 1.f / dot(v, v)); }
+
+template <bool STATS>
+__device__ __forceinline__ f3 illuminate(const DScene &sc, const qa_light &l, f3 p, uint32_t *stack, DCounters &cnt)
+{
+  const f3 intensity = ld3(l.intensity);
+  if (l.type == QA_LIGHT_DIRECT) {
+    Ray r;
+    r.p = p;
+    r.d = normalize(-ld3(l.direction));
+    return intensity * shadow<STATS>(sc, r, QA_BIGFLOAT, stack, cnt);
+  }
+  // point / spot
+  const f3 dir = ld3(l.position) - p;
+  Ray r;
+  r.p = p;
+  r.d = normalize(dir);
+  f3 I = (intensity * shadow<STATS>(sc, r, length(dir), stack, cnt)) * inverseSquareFalloff(dir);
+  if (l.type == QA_LIGHT_SPOT) {
+    // SpotLight::GetAttenuation(Direction(p)) (lights.cpp:128-143)
+    const f3 d = normalize(p - ld3(l.position));
+    const float cosTheta = dot(d, ld3(l.direction));
+    float att;
+    if (cosTheta < 0) att = 0;
+    else {
+      const float rr = qsqrt(1.f - cosTheta * cosTheta) / cosTheta;
+      if (rr > l.outer) att = 0;
+      else att = rr < l.inner ? 1.f : qpowf((l.outer - rr) / (l.outer - l.inner), 2.f);
+    }
+    I = I * att;
+  }
+  return I;
+}
+
+__device__ __forceinline__ f3 lightDirection(const qa_light &l, f3 p)
+{
+  if (l.type == QA_LIGHT_DIRECT) return ld3(l.direction);
+  return normalize(p - ld3(l.position));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane path state
+// ---------------------------------------------------------------------------------------------
+struct Path {
+  Ray ray;          // next ray to trace (world space)
+  f3 T;             // throughput
+  f3 L;             // radiance gathered by this sample so far
+  f3 absorb;        // absorption of the medium the current ray was spawned from (Beer's law on a
+                    // back-face exit, ComputeSecondaryRay :244-248)
+  int bounce;       // bounceCount the next hit is shaded with
+  bool fromDiffuse; // hInfo.c.hasDiffuseHit of the next hit
+  bool primary;     // camera ray
+};
+
+// ---------------------------------------------------------------------------------------------
+// The kernel
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const RenderParams rp)
+{
+  __shared__ uint32_t s_stack[QA_STACK * QA_BLOCK];
+  uint32_t *stack = s_stack + threadIdx.x;
+
+  // work items walk 8x8 pixel tiles (a wave starts on a compact screen patch); ragged right /
+  // bottom tiles contain padding slots that are simply skipped
+  const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
+  const unsigned tilesX = (unsigned) (rw + 7) / 8, tilesY = (unsigned) (rh + 7) / 8;
+  const unsigned total = tilesX * tilesY * 64u;
+  const unsigned lane = __lane_id();
+
+  DCounters cnt = {0, 0, 0, 0, 0, 0};
+
+  // pixel state
+  int px = 0, py = 0;
+  unsigned q = 0;           // region-local pixel index
+  uint32_t rng = 1;
+  int sidx = 0;
+  f3 mean = F3(0, 0, 0), cstd = F3(0, 0, 0);
+  float depth = 0.f;
+  Path path;
+  path.primary = true;
+  f3 texpos = F3(0, 0, 0);
+
+  bool alive = true, needPixel = true, needSample = false;
+
+  for (;;) {
+    // ---- A. pixel fetch: one atomic per wavefront for all lanes that ran out of work --------
+    const unsigned long long want = __ballot(alive && needPixel);
+    if (want) {
+      const unsigned n = (unsigned) __popcll(want);
+      unsigned base = 0;
+      const int leader = __ffsll((long long) want) - 1;
+      if ((int) lane == leader) base = (*rp.stop_flag) ? total : atomicAdd(rp.work_counter, n);
+      base = __shfl(base, leader);
+      if (alive && needPixel) {
+        const unsigned rank = (unsigned) __popcll(want & ((1ull << lane) - 1ull));
+        const unsigned w = base + rank;
+        if (base >= total || w >= total) {
+          alive = false;
+        } else {
+          const unsigned tile = w / 64, in = w % 64;
+          const unsigned tx = (tile % tilesX) * 8 + (in % 8), ty = (tile / tilesX) * 8 + (in / 8);
+          if (tx < (unsigned) rw && ty < (unsigned) rh) {
+            px = rp.x0 + (int) tx;
+            py = rp.y0 + (int) ty;
+            q = ty * (unsigned) rw + tx;
+            rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
+            sidx = 0;
+            mean = F3(0, 0, 0);
+            cstd = F3(0, 0, 0);
+            depth = 0.f;
+            needSample = true;
+            needPixel = false;
+          }
+          // else: padding slot of a ragged tile - ask again next iteration
+        }
+      }
+    }
+    if (!__any(alive)) break;
+
+    // ---- B. start a sample: camera ray (src/renderers/renderer.cpp:312-328) ------------------
+    if (alive && needSample) {
+      const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
+      texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
+      const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
+      const f3 cpt = (A + U * texpos.x) + V * texpos.y;
+      f3 campos = ld3(sc.cam.pos);
+      if (sc.cam.dof > 0.1f) {
+        // SuperSamplerHalton::NewDofSample (src/scene/scene.cpp:104-111)
+        const float r1 = rng1(rng), r2 = rng1(rng);
+        const float r = sc.cam.dof * qsqrt(r1);
+        const float t = r2 * 2.f * QA_PI;
+        campos = campos + (ld3(sc.cam.screenX) * (r * qcosf(t)) + ld3(sc.cam.screenY) * (r * qsinf(t)));
+      }
+      path.ray.p = campos;
+      path.ray.d = normalize(cpt - campos);
+      path.T = F3(1, 1, 1);
+      path.L = F3(0, 0, 0);
+      path.absorb = F3(0, 0, 0);
+      path.bounce = rp.max_bounce;
+      path.fromDiffuse = false;
+      path.primary = true;
+      needSample = false;
+      cnt.samples++;
+    }
+
+    // ---- C. trace ----------------------------------------------------------------------------
+    bool done = false;  // path finished in this iteration
+    if (alive && !needPixel) {
+      Hit h;
+      h.z = QA_BIGFLOAT;
+      h.node = -1;
+      h.mtlID = 0;
+      h.front = true;
+      h.p = F3(0, 0, 0);
+      h.N = F3(0, 0, 0);
+      const bool found = traceClosest<STATS>(sc, path.ray, h, stack, cnt);
+      if (path.primary && sidx == 0) depth = found ? h.z : QA_BIGFLOAT;
+
+      if (!found) {
+        // background for camera rays (renderer.cpp:337-341), environment otherwise
+        // (MtlBlinn_PhotonMap.cpp:249-251); textured versions are rejected at upload
+        const f3 c = path.primary ? ld3(sc.background.color) : ld3(sc.environment.color);
+        path.L = path.L + path.T * c;
+        done = true;
+      } else {
+        // ---- D. shade: MtlBlinn_PhotonMap::Shade (MtlBlinn_PhotonMap.cpp:256-500) -----------
+        // Beer-Lambert attenuation of everything this hit returns, when the ray arrives from
+        // inside (ComputeSecondaryRay :244-248)
+        if (!path.primary && !h.front) {
+          const f3 att = F3(qexpf(-path.absorb.x * h.z), qexpf(-path.absorb.y * h.z), qexpf(-path.absorb.z * h.z));
+          path.T = path.T * att;
+        }
+        const qa_instance &in = sc.inst[h.node];
+        const qa_material *mp = nullptr;
+        bool white = false;
+        if (in.mtlset >= 0) {
+          const qa_mtlset ms = sc.mtlset[in.mtlset];
+          if (ms.multi) {
+            if (h.mtlID >= 0 && h.mtlID < ms.count) mp = &sc.mtl[ms.first + h.mtlID];
+            else white = true;  // MultiMtl::Shade returns (1,1,1) (materials.h:70-76)
+          } else mp = &sc.mtl[ms.first];
+        }
+        if (mp == nullptr) {
+          if (white) path.L = path.L + path.T;
+          done = true;
+        } else {
+          const qa_material &m = *mp;
+          const f3 V = -path.ray.d;
+          const f3 N = h.N;
+          const f3 Y = dot(N, V) > 0.f ? N : -N;
+          const f3 p = h.p;
+          const f3 tK = ld3(m.refraction.color), rK = ld3(m.reflection.color);
+          const f3 sampleSpecular = ld3(m.specular.color);
+          const f3 sampleDiffuse = ld3(m.diffuse.color);
+          path.L = path.L + path.T * ld3(m.emission.color);
+
+          // ComputeFresnel (:65-105); skipped when neither lobe can receive energy: with
+          // tK = rK = 0 both products below are exactly 0 for any finite Fresnel term.
+          f3 sampleTransmission = F3(0, 0, 0), sampleReflection = F3(0, 0, 0);
+          f3 tDir = F3(0, 0, 0), rDir = F3(0, 0, 0);
+          const bool specularLobes = (tK.x != 0.f || tK.y != 0.f || tK.z != 0.f || rK.x != 0.f || rK.y != 0.f || rK.z != 0.f);
+          if (specularLobes) {
+            const f3 Z = cross(V, Y);
+            const f3 X = normalize(cross(Y, Z));
+            const float nIOR = h.front ? 1.f / m.ior : m.ior;
+            const float cosI = dot(N, V);
+            const float sinI = qsqrt(1 - cosI * cosI);
+            const float sinO = qmax(0.f, qmin(1.f, sinI * nIOR));
+            const float cosO = qsqrt(1.f - sinO * sinO);
+            tDir = ((-X) * sinO) - (Y * cosO);
+            rDir = ((N * 2.f) * dot(N, V)) - V;
+            const bool totReflection = (nIOR * sinI) > 1.001f;
+            const float C = (nIOR - 1.f) * (nIOR - 1.f) / ((nIOR + 1.f) * (nIOR + 1.f));
+            const float rC = C + (1.f - C) * qpowf(1.f - qabs(cosI), 5.f);
+            const float tC = 1.f - rC;
+            sampleTransmission = totReflection ? F3(0, 0, 0) : tK * tC;
+            sampleReflection = totReflection ? (rK + tK) : (rK + tK * rC);
+          }
+
+          // RandomSelectMtl (:107-150): one draw, luma-weighted lobes + Russian roulette
+          const float lumaT = luma(sampleTransmission), lumaR = luma(sampleReflection), lumaD = luma(sampleDiffuse);
+          const float rsel = rng1(rng);
+          const float coefTransmit = lumaT;
+          const float coefReflection = coefTransmit + lumaR;
+          const float coefDiffuse = coefReflection + lumaD;
+          const float coefSum = coefDiffuse + m.kill;
+          const float sel = rsel * coefSum;
+          int select;  // 0 transmit, 1 reflect, 2 diffuse, 3 absorb
+          if (sel < coefTransmit && lumaT > 0.00001f) select = 0;
+          else if (sel < coefReflection && lumaR > 0.00001f) select = 1;
+          else if (sel < coefDiffuse && lumaD > 0.00001f) select = 2;
+          else select = 3;
+
+          // secondary ray (at most one): reflect / transmit / diffuse blocks (:374-479)
+          bool spawn = false;
+          f3 nextDir = F3(0, 0, 0), bxdf = F3(0, 0, 0);
+          bool nextFromDiffuse = false;
+          if (path.bounce > 0) {
+            if (select == 1 && lumaR > 0.00001f) {
+              if (m.gloss_refl > 0.f) {
+                do { nextDir = normalize(normalize(rDir) + uniformBall(rng, 2.f * m.gloss_refl)); } while (dot(nextDir, Y) < 0);
+              } else nextDir = rDir;
+              bxdf = sampleReflection;
+              spawn = true;
+            } else if (select == 0 && lumaT > 0.00001f) {
+              if (m.gloss_refr > 0.f) {
+                do { nextDir = normalize(normalize(tDir) + uniformBall(rng, 2.f * m.gloss_refr)); } while (dot(nextDir, Y) > 0);
+              } else nextDir = tDir;
+              bxdf = sampleTransmission;
+              spawn = true;
+            } else if (select == 2 && lumaD > 0.00001f && !path.fromDiffuse && h.front) {
+              // SampleDiffuseBxDF (:199-224) + CosWeightedHemisphere (src/core/sampler.cpp:87-103)
+              const float r1 = rng1(rng), r2 = rng1(rng);
+              const float cosTheta = qsqrt(r1);
+              const float sinTheta = qsqrt(1 - r1);
+              const float phi = 2 * QA_PI * r2;
+              const f3 smp = F3(sinTheta * qcosf(phi), sinTheta * qsinf(phi), cosTheta);
+              nextDir = toLocalFrame(N, smp);
+              bxdf = sampleDiffuse;
+              if (sampleSpecular.x != 0.f || sampleSpecular.y != 0.f || sampleSpecular.z != 0.f) {
+                const f3 Ld = normalize(nextDir);
+                const f3 H = normalize(V + Ld);
+                const float cosNH = qmax(0.f, dot(N, H));
+                bxdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, m.gloss_spec);
+              }
+              nextFromDiffuse = true;
+              spawn = true;
+            }
+          }
+
+          // direct lighting (:481-498): every non-ambient light, weight 1/#lights (ambient counted)
+          if (sc.num_lights > 0) {
+            const float normCoefDI = 1.f / (float) sc.num_lights;
+            for (int li = 0; li < sc.num_lights; ++li) {
+              const qa_light &l = sc.light[li];
+              if (l.type == QA_LIGHT_AMBIENT) continue;
+              const f3 intensity = illuminate<STATS>(sc, l, p, stack, cnt) * normCoefDI;
+              const f3 Ld = normalize(-lightDirection(l, p));
+              const f3 H = normalize(V + Ld);
+              const float cosNL = qmax(0.f, dot(N, Ld));
+              const float cosNH = qmax(0.f, dot(N, H));
+              const f3 brdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, m.gloss_spec);
+              path.L = path.L + path.T * ((intensity * cosNL) * brdf);
+            }
+          }
+
+          if (spawn) {
+            // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
+            path.ray.p = p;
+            path.ray.d = normalize(nextDir);
+            path.T = path.T * bxdf;
+            path.absorb = ld3(m.absorption);
+            path.bounce -= 1;
+            path.fromDiffuse = nextFromDiffuse;
+            path.primary = false;
+          } else {
+            done = true;
+          }
+        }
+      }
+    }
+
+    // ---- E. sample finished: SuperSamplerHalton::Accumulate / Loop (scene.cpp:92-121) ---------
+    if (alive && done) {
+      const float inv = (float) (sidx + 1);
+      const f3 dc = (path.L - mean) / inv;
+      mean = mean + dc;
+      if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
+      ++sidx;
+      const bool more = sidx < rp.spp_min ||
+                        (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
+      if (more) {
+        needSample = true;
+      } else {
+        rp.rgb[3 * q + 0] = mean.x;
+        rp.rgb[3 * q + 1] = mean.y;
+        rp.rgb[3 * q + 2] = mean.z;
+        rp.depth[q] = depth;
+        rp.ns[q] = (uint32_t) sidx;
+        cnt.pixels++;
+        needPixel = true;
+      }
+    }
+  }
+
+  // ---- counters: wave reduction, one atomic per wave and counter -----------------------------
+  unsigned long long v[6] = {cnt.samples, cnt.casts_normal, cnt.casts_shadow, cnt.bvh_nodes, cnt.tri_tests, cnt.pixels};
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(rp.counters);
+  for (int i = 0; i < 6; ++i) {
+    unsigned long long x = v[i];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if (lane == 0 && x) atomicAdd(&dst[i], x);
+  }
+}
+
+}  // namespace qa

@@ -1,0 +1,160 @@
+"""ctypes binding of libqaray_hip.so (include/qaray_hip.h) - the MI355X integrator.
+
+There is no CPU fallback: creating a context without the library or without a GPU raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "lib", "libqaray_hip.so")
+
+QA_RENDER_STATS = 1
+DEFAULT_SEED = 0x51A7A7
+
+
+class Counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("casts_normal", C.c_uint64), ("casts_shadow", C.c_uint64),
+                ("bvh_nodes", C.c_uint64), ("tri_tests", C.c_uint64), ("pixels", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libqaray_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(
+                f"{HIP_LIB_PATH} is missing: the HIP extension is the product path and has no fallback - "
+                "build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C qaray_amd/csrc hip`")
+        L = C.CDLL(HIP_LIB_PATH)
+        L.qa_last_error.restype = C.c_char_p
+        L.qa_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.qa_ctx_destroy.argtypes = [C.c_void_p]
+        L.qa_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.qa_scene_upload_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.qa_render_region.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qa_render_region_device.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_uint32, C.c_void_p,
+                                                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qa_synchronize.argtypes = [C.c_void_p]
+        L.qa_request_stop.argtypes = [C.c_void_p]
+        L.qa_clear_stop.argtypes = [C.c_void_p]
+        L.qa_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.qa_reset_counters.argtypes = [C.c_void_p]
+        L.qa_get_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.qa_reset_kernel_time.argtypes = [C.c_void_p]
+        L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipError(rc, lib().qa_last_error().decode())
+
+
+class Context:
+    """One integrator context = one GPU (the reference's Renderer instance on one MPI rank)."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        _check(lib().qa_ctx_create(int(device_id), C.byref(self._h)))
+        self.device_id = int(device_id)
+        self.size = None
+
+    # -- scene ---------------------------------------------------------------------------------
+    def upload_scene(self, blob):
+        """blob: numpy uint8 array (host) holding a flat scene."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        _check(lib().qa_scene_upload(self._h, blob.ctypes.data, blob.size))
+        self._remember_size(blob)
+
+    def upload_scene_device(self, dev_tensor):
+        """dev_tensor: torch uint8 CUDA tensor holding a flat scene (e.g. after a broadcast)."""
+        assert dev_tensor.is_cuda and dev_tensor.is_contiguous()
+        _check(lib().qa_scene_upload_device(self._h, dev_tensor.data_ptr(), dev_tensor.numel()))
+        self._remember_size(dev_tensor[:256].cpu().numpy())
+
+    def _remember_size(self, blob_head):
+        # qa_flat_header: width/height follow magic,version(8) total_bytes(8) 6 vec3 (72) dof (4)
+        w, h = np.frombuffer(bytes(bytearray(blob_head[92:100])), dtype=np.uint32)
+        self.size = (int(w), int(h))
+
+    # -- rendering -----------------------------------------------------------------------------
+    def render_region(self, region, spp, max_bounce=5, seed=DEFAULT_SEED, spp_max=None, stats=False):
+        """Synchronous render into host arrays: -> (rgb[h,w,3] f32, depth[h,w] f32, ns[h,w] u32)."""
+        x0, y0, x1, y1 = region
+        h, w = y1 - y0, x1 - x0
+        rgb = np.zeros((h, w, 3), np.float32)
+        depth = np.zeros((h, w), np.float32)
+        ns = np.zeros((h, w), np.uint32)
+        spp_max = spp if spp_max is None else spp_max
+        _check(lib().qa_render_region(self._h, x0, y0, x1, y1, spp, spp_max, max_bounce, seed,
+                                      QA_RENDER_STATS if stats else 0, rgb.ctypes.data, depth.ctypes.data,
+                                      ns.ctypes.data))
+        return rgb, depth, ns
+
+    def render_region_device(self, region, spp, rgb, depth, ns, max_bounce=5, seed=DEFAULT_SEED, spp_max=None,
+                             stats=False, stream=None):
+        """Asynchronous render into torch CUDA tensors (float32 [h,w,3], float32 [h,w], int32/uint32 [h,w])."""
+        x0, y0, x1, y1 = region
+        n = (x1 - x0) * (y1 - y0)
+        assert rgb.is_cuda and rgb.is_contiguous() and rgb.numel() == 3 * n and rgb.element_size() == 4
+        assert depth.is_cuda and depth.is_contiguous() and depth.numel() == n and depth.element_size() == 4
+        assert ns.is_cuda and ns.is_contiguous() and ns.numel() == n and ns.element_size() == 4
+        spp_max = spp if spp_max is None else spp_max
+        sptr = C.c_void_p(stream) if stream else None
+        _check(lib().qa_render_region_device(self._h, x0, y0, x1, y1, spp, spp_max, max_bounce, seed,
+                                             QA_RENDER_STATS if stats else 0, rgb.data_ptr(), depth.data_ptr(),
+                                             ns.data_ptr(), sptr))
+
+    def synchronize(self):
+        _check(lib().qa_synchronize(self._h))
+
+    def request_stop(self):
+        _check(lib().qa_request_stop(self._h))
+
+    def clear_stop(self):
+        _check(lib().qa_clear_stop(self._h))
+
+    # -- measurement ---------------------------------------------------------------------------
+    def counters(self):
+        c = Counters()
+        _check(lib().qa_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        _check(lib().qa_reset_counters(self._h))
+
+    def kernel_time(self):
+        """-> (total_ms, launches) of the integrator kernel since the last reset (HIP events)."""
+        ms, n = C.c_double(), C.c_uint64()
+        _check(lib().qa_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_kernel_time(self):
+        _check(lib().qa_reset_kernel_time(self._h))
+
+    def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
+        _check(lib().qa_set_launch_config(self._h, blocks_per_cu, threads_per_block))
+
+    def close(self):
+        if self._h:
+            lib().qa_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
