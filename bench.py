@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X qaray hot path.
+
+Metric (BASELINE.json): Msamples/s (1 sample = 1 camera path) and wall-clock to 1080p@512spp, with
+the kernel's fraction of the HBM roofline, at 1/2/4/8 GPUs.
+
+A "step" renders ONE frame of inputs/example_project12_box.xml (Cornell box, BASELINE config[1]) at
+512 spp.  N=1: 1920x1080.  N>1 (weak scaling in resolution, per-GPU pixel count fixed): the same view
+at 16:9 with N x 2.07 Mpixel (N=4 is exactly 3840x2160), 8-row strips dealt round-robin to the ranks,
+scene blob broadcast from rank 0 over RCCL, float radiance strips gathered to rank 0 inside the step.
+Inputs (scene tables) are resident in HBM before the timed region.
+
+One JSON line on rank 0; see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BYTES_PER_CAST = 144   # ray 2x32 B + hit 2x16 B + path state 2x24 B
+BYTES_PER_SAMPLE = 24  # radiance accumulate read + write
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def frame_size(n_gpus, base_w, base_h):
+    if n_gpus == 1:
+        return base_w, base_h
+    s = math.sqrt(n_gpus)
+    return int(round(base_w * s)), int(round(base_h * s))
+
+
+def cpu_baseline(scene_xml, width, height, spp, seed):
+    """Reference CPU renderer (oracle/_ref/ref_harness, the reference's own code built from its
+    sources) timed on this host's cores on a bounded sample of the same workload: the same frame
+    at `spp` samples per pixel.  Falls back to the C restatement ("port") when the reference binary
+    did not travel."""
+    cores = os.cpu_count() or 1
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    sample = f"{os.path.basename(scene_xml)} {width}x{height} at {spp} spp (same frame, fewer spp), seed {seed:#x}"
+    if os.path.exists(harness):
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "cpu")
+            cmd = [harness, os.path.basename(scene_xml), "--size", str(width), str(height), "--spp", str(spp),
+                   "--threads", str(cores), "--seed", str(seed), "--out", out]
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+            r = subprocess.run(cmd, cwd=os.path.dirname(scene_xml), env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True)
+            if r.returncode == 0:
+                meta = json.load(open(out + ".json"))
+                return {"value": meta["msamples_per_s"], "unit": "Msamples/s", "cores": int(meta["threads"]),
+                        "kind": "reference", "sample": sample, "seconds": meta["seconds"]}
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    blob = load_scene_blob(scene_xml, size=(width, height))
+    t0 = time.time()
+    _, _, _, cnt = oracle.render(blob, (0, 0, width, height), spp, seed=seed, threads=cores)
+    dt = time.time() - t0
+    return {"value": cnt.samples / dt * 1e-6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": sample, "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="example_project12_box.xml")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--bounce", type=int, default=5)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x51A7A7)
+    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--save-png", default=None, help="rank 0: write the last frame through FrameBuffer")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qaray_amd import distributed as qd
+    from qaray_amd import hip
+    from qaray_amd.host import SCENES_DIR, FrameBuffer, load_scene_blob
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    W, H = frame_size(world, args.width, args.height)
+    scene_xml = args.scene if os.path.isabs(args.scene) else os.path.join(SCENES_DIR, args.scene)
+
+    ctx = hip.Context(local_rank)
+    # rank 0 parses + flattens; everyone receives the blob over RCCL and adopts it from HBM
+    blob = load_scene_blob(scene_xml, size=(W, H)) if rank == 0 else None
+    if world > 1:
+        dblob = qd.broadcast_blob(blob, device, src=0)
+    else:
+        dblob = torch.from_numpy(blob).to(device)
+    ctx.upload_scene_device(dblob)
+
+    nstrips = hip.strip_count(0, H, rank, world)
+    maxstrips = qd.max_strips_per_rank(H, world)
+    rows = maxstrips * qd.STRIP_ROWS          # equal shapes on every rank for the gather
+    rgb = torch.zeros((rows, W, 3), dtype=torch.float32, device=device)
+    depth = torch.zeros((rows, W), dtype=torch.float32, device=device)
+    ns = torch.zeros((rows, W), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    nown = nstrips * qd.STRIP_ROWS
+    full = None
+
+    def step():
+        nonlocal full
+        if nstrips:
+            ctx.render_strips_device((0, 0, W, H), rank, world, args.spp, rgb[:nown], depth[:nown], ns[:nown],
+                                     max_bounce=args.bounce, seed=args.seed, stream=stream)
+        if world > 1:
+            g = qd.gather_packed(rgb, dst=0)
+            if rank == 0:
+                full = qd.assemble(g, H, world)
+        else:
+            full = rgb[:H]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.reset_kernel_time()
+    ctx.reset_counters()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms, launches = ctx.kernel_time()
+    cnt = ctx.counters()
+    local = torch.tensor([cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+    samples, casts_n, casts_s = (float(v) for v in local.tolist())
+
+    if rank == 0:
+        msamples = samples / elapsed * 1e-6
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the dominant (only) kernel, rank 0's launches: ALGORITHMIC bytes per launch /
+        # average launch duration measured with HIP events on the launch stream
+        k_samples = cnt["samples"] / max(launches, 1)
+        k_casts = (cnt["casts_normal"] + cnt["casts_shadow"]) / max(launches, 1)
+        k_bytes = k_casts * BYTES_PER_CAST + k_samples * BYTES_PER_SAMPLE
+        k_ms = kernel_ms / max(launches, 1)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/s (1 sample = 1 camera path), Cornell box 1080p@512spp",
+            "value": msamples, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"inputs/{os.path.basename(scene_xml)} (Cornell box, tinyobjloader cornell_box.obj, 36 triangles)"
+                                   f", {W}x{H}, {args.spp} spp, maxBounce {args.bounce}, seed {args.seed:#x}",
+                       "frame": [W, H], "spp": args.spp, "partition": f"8-row strips round-robin over {world} GPU(s)",
+                       "wall_clock_s_per_frame": ms_per_step * 1e-3,
+                       "casts_per_sample": (casts_n + casts_s) / max(samples, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "qa::qa_integrate<false>", "kernel_ms_avg": k_ms, "launches": int(launches),
+                         "algorithmic_bytes_per_launch": k_bytes,
+                         "note": "algorithmic bytes = casts x 144 B + samples x 24 B (SURVEY.md 8d); path state "
+                                 "actually lives in VGPRs/LDS, so measured HBM traffic is far below this"},
+        }
+        if world == 1 and args.cpu_spp > 0:
+            out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, args.cpu_spp, args.seed)
+        if args.save_png:
+            fb = FrameBuffer(W, H)
+            fb.deposit(0, 0, W, H, full.cpu().numpy(), np.zeros((H, W), np.float32),
+                       np.full((H, W), args.spp, np.uint32), args.spp, use_srgb=True)
+            fb.save_image(args.save_png)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

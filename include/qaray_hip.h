@@ -17,6 +17,8 @@
  *                                  camera ray, Scene::TraceNodeNormal, Material::Shade,
  *                                  Light::Illuminate/GenLight::Shadow, SuperSamplerHalton
  *                                                                       src/renderers/renderer.cpp:302-423
+ *   qa_render_strips_device        Renderer_MPI's rank-strided ThreadRender (every rank renders
+ *                                  tiles rank, rank+size, ...)          src/renderers/renderer.cpp:383-387
  *   qa_request_stop / qa_clear_stop   tasking::signal_stop / signal_start  src/tasking/parallel_for.cpp:70-73
  *   qa_get_counters                (no counterpart: the reference only prints wall-clock)
  *   qa_get_kernel_time             Renderer::StartTimer/StopTimer       src/renderers/renderer.cpp:42-63
@@ -67,6 +69,18 @@ int qa_render_region(qa_ctx *ctx, int x0, int y0, int x1, int y1, int spp_min, i
 int qa_render_region_device(qa_ctx *ctx, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
                             int max_bounce, uint32_t seed, uint32_t flags, float *d_rgb,
                             float *d_depth, uint32_t *d_nsamples, void *hip_stream);
+/* Image-space partition between GPUs.  The region is cut into horizontal strips of QA_STRIP_ROWS
+ * (8) pixel rows; this call renders strips first_strip, first_strip + strip_step, ... (rank r of
+ * n: first_strip = r, strip_step = n), i.e. the reference's round-robin tile ownership
+ *   tasking::parallel_for(tileStart = mpiRank, tileStop, tileStep = mpiSize)   src/renderers/renderer.cpp:383-387
+ * Outputs are PACKED strip after strip: row (k*8 + i) of the buffers is row
+ * y0 + (first_strip + k*strip_step)*8 + i of the image; buffers hold qa_strip_count()*8 rows of
+ * (x1-x0) pixels (rows of a ragged last strip that fall below y1 keep nsamples = 0). */
+#define QA_STRIP_ROWS 8
+int qa_render_strips_device(qa_ctx *ctx, int x0, int y0, int x1, int y1, int first_strip, int strip_step,
+                            int spp_min, int spp_max, int max_bounce, uint32_t seed, uint32_t flags,
+                            float *d_rgb, float *d_depth, uint32_t *d_nsamples, void *hip_stream);
+int qa_strip_count(int y0, int y1, int first_strip, int strip_step);
 /* Wait for everything enqueued by this context. */
 int qa_synchronize(qa_ctx *ctx);
 
@@ -85,6 +99,12 @@ int qa_reset_kernel_time(qa_ctx *ctx);
 int qa_set_launch_config(qa_ctx *ctx, int blocks_per_cu, int threads_per_block);
 
 const char *qa_last_error(void);
+
+/* Self-test hooks for the device math library (qaray_amd/csrc/hip/qa_device_math.h): the device
+ * sinf/cosf evaluated on the GPU, and the same source compiled for the host (fn: 0 sinf, 1 cosf,
+ * 2 powf(x,y), 3 expf). */
+int qa_test_sincosf_device(const float *x, int n, float *s, float *c);
+int qa_test_math_host(int fn, const float *x, const float *y, int n, float *out);
 
 #ifdef __cplusplus
 }

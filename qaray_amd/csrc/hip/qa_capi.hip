@@ -262,8 +262,15 @@ static void Launch(qa_ctx *c, const RenderParams &rp, int blocks, hipStream_t s)
   hipLaunchKernelGGL(qa_integrate<STATS>, dim3((unsigned) blocks), dim3(QA_BLOCK), 0, s, c->ds, rp);
 }
 
-static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int spp_max, int max_bounce,
-                  uint32_t seed, uint32_t flags, float *d_rgb, float *d_depth, uint32_t *d_ns, hipStream_t s)
+static int OwnTileRows(int y0, int y1, int tile_row0, int tile_row_step)
+{
+  const int tilesY = (y1 - y0 + 7) / 8;
+  if (tile_row0 >= tilesY) return 0;
+  return (tilesY - tile_row0 + tile_row_step - 1) / tile_row_step;
+}
+
+static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int tile_row_step, int spp_min, int spp_max,
+                  int max_bounce, uint32_t seed, uint32_t flags, float *d_rgb, float *d_depth, uint32_t *d_ns, hipStream_t s)
 {
   if (!c->haveScene) return Fail(QA_ENOSCENE, "no scene uploaded");
   if (x0 < 0 || y0 < 0 || x1 > c->ds.cam.width || y1 > c->ds.cam.height || x1 <= x0 || y1 <= y0)
@@ -275,8 +282,12 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int sp
   c->ds.halton = c->dHalton;
   c->ds.halton_count = c->haltonCount;
 
-  const size_t npix = (size_t) (x1 - x0) * (y1 - y0);
-  // pixels skipped by a stop request must read as "not rendered"
+  if (tile_row0 < 0 || tile_row_step < 1) return Fail(QA_EINVAL, "bad strip partition");
+  const int ownRows = OwnTileRows(y0, y1, tile_row0, tile_row_step);
+  if (ownRows == 0) return QA_OK;  // nothing to do for this rank
+  const bool whole = (tile_row0 == 0 && tile_row_step == 1);
+  const size_t npix = (size_t) (x1 - x0) * (whole ? (size_t) (y1 - y0) : (size_t) ownRows * 8);
+  // pixels skipped by a stop request (and the padding rows of a ragged last strip) read as "not rendered"
   HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
   unsigned int *work = c->dWork + c->workNext;
   c->workNext = (c->workNext + 1) % qa_ctx::kCounterRing;
@@ -286,12 +297,13 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int sp
   rp.x0 = x0; rp.y0 = y0; rp.x1 = x1; rp.y1 = y1;
   rp.spp_min = spp_min; rp.spp_max = spp_max; rp.max_bounce = max_bounce;
   rp.seed = seed;
+  rp.tile_row0 = tile_row0; rp.tile_row_step = tile_row_step; rp.own_tile_rows = ownRows; rp.pad = 0;
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
   rp.stop_flag = c->dStopAlias;
   rp.counters = c->dCounters;
 
-  const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ((y1 - y0 + 7) / 8);
+  const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ownRows;
   const long long needBlocks = ((long long) tiles * 64 + QA_BLOCK - 1) / QA_BLOCK;
   long long blocks = (long long) c->numCUs * c->blocksPerCU;
   if (blocks > needBlocks) blocks = needBlocks;
@@ -323,7 +335,45 @@ static int DrainEvents(qa_ctx *c)
   return QA_OK;
 }
 
+__global__ void qa_sincos_probe(const float *x, int n, float *s, float *c)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { s[i] = qsinf(x[i]); c[i] = qcosf(x[i]); }
+}
+
 extern "C" {
+
+// Self-test hooks: the device math next to the host libm (tests/test_gpu_parity.py, tests/test_device_math.py)
+int qa_test_sincosf_device(const float *x, int n, float *s, float *c)
+{
+  if (!x || !s || !c || n <= 0) return Fail(QA_EINVAL, "bad argument");
+  float *dx = nullptr, *dsn = nullptr, *dcs = nullptr;
+  HIP_TRY(hipMalloc((void **) &dx, n * sizeof(float)));
+  HIP_TRY(hipMalloc((void **) &dsn, n * sizeof(float)));
+  HIP_TRY(hipMalloc((void **) &dcs, n * sizeof(float)));
+  HIP_TRY(hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qa_sincos_probe, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, dsn, dcs);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(s, dsn, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(c, dcs, n * sizeof(float), hipMemcpyDeviceToHost));
+  (void) hipFree(dx); (void) hipFree(dsn); (void) hipFree(dcs);
+  return QA_OK;
+}
+// the same source compiled for the host (no GPU needed)
+int qa_test_math_host(int fn, const float *x, const float *y, int n, float *out)
+{
+  if (!x || !out || n <= 0) return QA_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: out[i] = qsinf(x[i]); break;
+      case 1: out[i] = qcosf(x[i]); break;
+      case 2: out[i] = qpowf(x[i], y ? y[i] : 1.f); break;
+      case 3: out[i] = qexpf(x[i]); break;
+      default: return QA_EINVAL;
+    }
+  }
+  return QA_OK;
+}
 
 const char *qa_last_error(void) { return g_err.c_str(); }
 
@@ -351,6 +401,10 @@ int qa_ctx_create(int device_id, qa_ctx **out)
     return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
   }
   *c->hStop = 0;
+  // persistent grid = what is resident at once (VGPR/LDS-limited blocks per CU x CUs)
+  int resident = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, qa_integrate<false>, QA_BLOCK, 0) == hipSuccess && resident > 0)
+    c->blocksPerCU = resident > 8 ? 8 : resident;
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
@@ -416,7 +470,23 @@ int qa_render_region_device(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_m
   if (!c) return Fail(QA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
-  return Render(c, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
+  return Render(c, x0, y0, x1, y1, 0, 1, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
+}
+
+int qa_render_strips_device(qa_ctx *c, int x0, int y0, int x1, int y1, int first_strip, int strip_step, int spp_min,
+                            int spp_max, int max_bounce, uint32_t seed, uint32_t flags, float *d_rgb, float *d_depth,
+                            uint32_t *d_ns, void *hip_stream)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  return Render(c, x0, y0, x1, y1, first_strip, strip_step, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
+}
+
+int qa_strip_count(int y0, int y1, int first_strip, int strip_step)
+{
+  if (y1 <= y0 || first_strip < 0 || strip_step < 1) return 0;
+  return OwnTileRows(y0, y1, first_strip, strip_step);
 }
 
 int qa_render_region(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int spp_max, int max_bounce,
@@ -438,7 +508,7 @@ int qa_render_region(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int
     HIP_TRY(hipMalloc((void **) &c->dNs, npix * sizeof(uint32_t)));
     c->stagePixels = npix;
   }
-  const int rc = Render(c, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed, flags, c->dRgb, c->dDepth, c->dNs, c->stream);
+  const int rc = Render(c, x0, y0, x1, y1, 0, 1, spp_min, spp_max, max_bounce, seed, flags, c->dRgb, c->dDepth, c->dNs, c->stream);
   if (rc != QA_OK) return rc;
   HIP_TRY(hipMemcpyAsync(rgb, c->dRgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(depth, c->dDepth, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));

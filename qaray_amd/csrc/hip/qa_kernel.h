@@ -411,8 +411,11 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
   // work items walk 8x8 pixel tiles (a wave starts on a compact screen patch); ragged right /
   // bottom tiles contain padding slots that are simply skipped
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
-  const unsigned tilesX = (unsigned) (rw + 7) / 8, tilesY = (unsigned) (rh + 7) / 8;
-  const unsigned total = tilesX * tilesY * 64u;
+  // A launch may own only every tile_row_step-th 8-row strip of the region (round-robin image
+  // partition between GPUs, the reference's ThreadRender(tileStart=rank, step=size),
+  // src/renderers/renderer.cpp:383-387); its outputs are packed strip after strip.
+  const unsigned tilesX = (unsigned) (rw + 7) / 8;
+  const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
   const unsigned lane = __lane_id();
 
   DCounters cnt = {0, 0, 0, 0, 0, 0};
@@ -446,11 +449,13 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
           alive = false;
         } else {
           const unsigned tile = w / 64, in = w % 64;
-          const unsigned tx = (tile % tilesX) * 8 + (in % 8), ty = (tile / tilesX) * 8 + (in / 8);
+          const unsigned otr = tile / tilesX;  // index among the strips this launch owns
+          const unsigned tx = (tile % tilesX) * 8 + (in % 8);
+          const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
           if (tx < (unsigned) rw && ty < (unsigned) rh) {
             px = rp.x0 + (int) tx;
             py = rp.y0 + (int) ty;
-            q = ty * (unsigned) rw + tx;
+            q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
             rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
             sidx = 0;
             mean = F3(0, 0, 0);

@@ -83,6 +83,7 @@ struct RenderParams {
   int32_t x0, y0, x1, y1;      // region
   int32_t spp_min, spp_max, max_bounce;
   uint32_t seed;
+  int32_t tile_row0, tile_row_step, own_tile_rows, pad;  // which 8-row strips of the region
   float *rgb;                  // region-local outputs
   float *depth;
   uint32_t *ns;

@@ -1,0 +1,72 @@
+"""Image-space partition across ranks (one process per GPU), mirroring the reference's MPI mode:
+every rank renders tiles rank, rank+size, ... (src/renderers/renderer.cpp:383-387) and rank 0
+gathers and places them (src/renderers/Renderer_MPI.cpp:142-207).  Differences by design:
+the flattened scene is BROADCAST from rank 0 as one blob (the reference re-parses the XML on every
+rank), the partition unit is an 8-row strip, and the gather moves float radiance, not 8-bit pixels.
+
+The functions here are transport-only (torch.distributed: "nccl" = RCCL on GPUs, "gloo" on CPU) and
+take the renderer as a callable, so the N>1 logic is testable without a GPU."""
+import numpy as np
+
+STRIP_ROWS = 8
+
+
+def num_strips(height):
+    return (height + STRIP_ROWS - 1) // STRIP_ROWS
+
+
+def own_strips(height, world, rank):
+    """Strip indices owned by `rank` (round-robin)."""
+    return list(range(rank, num_strips(height), world))
+
+
+def max_strips_per_rank(height, world):
+    return (num_strips(height) + world - 1) // world
+
+
+def place_strips(full, packed, height, world, rank):
+    """Copy rank's packed strips (rows k*8..k*8+7 = strip rank+k*world) into the full image (numpy or
+    torch, first axis = rows).  The analogue of PlaceImage<T> (Renderer_MPI.cpp:103-122)."""
+    for k, s in enumerate(own_strips(height, world, rank)):
+        r0 = s * STRIP_ROWS
+        n = min(STRIP_ROWS, height - r0)
+        full[r0:r0 + n] = packed[k * STRIP_ROWS:k * STRIP_ROWS + n]
+    return full
+
+
+def broadcast_blob(blob_np, device, src=0):
+    """Rank `src` passes its flat scene (numpy uint8); every rank returns a uint8 tensor on `device`
+    holding the same bytes.  One size broadcast + one payload broadcast."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    n = torch.tensor([blob_np.size if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    if rank == src:
+        t = torch.from_numpy(np.ascontiguousarray(blob_np)).to(device)
+    else:
+        t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return t
+
+
+def gather_packed(packed, dst=0):
+    """Gather equally-shaped packed strip tensors to rank `dst` -> list of tensors (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if world == 1:
+        return [packed]
+    out = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, gather_list=out, dst=dst)
+    return out
+
+
+def assemble(gathered, height, world):
+    """Rank 0: list of packed per-rank tensors -> full image tensor [height, ...]."""
+    import torch
+    first = gathered[0]
+    full = torch.empty((height,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+    for r in range(world):
+        place_strips(full, gathered[r], height, world, r)
+    return full

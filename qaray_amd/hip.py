@@ -46,6 +46,9 @@ def lib():
         L.qa_render_region.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.qa_render_region_device.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_uint32, C.c_void_p,
                                                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qa_render_strips_device.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_uint32, C.c_uint32, C.c_void_p,
+                                                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qa_strip_count.argtypes = [C.c_int] * 4
         L.qa_synchronize.argtypes = [C.c_void_p]
         L.qa_request_stop.argtypes = [C.c_void_p]
         L.qa_clear_stop.argtypes = [C.c_void_p]
@@ -61,6 +64,10 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise HipError(rc, lib().qa_last_error().decode())
+
+
+def strip_count(y0, y1, first_strip, strip_step):
+    return int(lib().qa_strip_count(y0, y1, first_strip, strip_step))
 
 
 class Context:
@@ -117,6 +124,21 @@ class Context:
         _check(lib().qa_render_region_device(self._h, x0, y0, x1, y1, spp, spp_max, max_bounce, seed,
                                              QA_RENDER_STATS if stats else 0, rgb.data_ptr(), depth.data_ptr(),
                                              ns.data_ptr(), sptr))
+
+    def render_strips_device(self, region, first_strip, strip_step, spp, rgb, depth, ns, max_bounce=5,
+                             seed=DEFAULT_SEED, spp_max=None, stats=False, stream=None):
+        """Render strips first_strip, first_strip+strip_step, ... (8 rows each) of `region` into PACKED
+        torch CUDA tensors of strip_count(...)*8 rows."""
+        x0, y0, x1, y1 = region
+        n = strip_count(y0, y1, first_strip, strip_step) * 8 * (x1 - x0)
+        assert rgb.is_cuda and rgb.is_contiguous() and rgb.numel() == 3 * n and rgb.element_size() == 4
+        assert depth.is_cuda and depth.is_contiguous() and depth.numel() == n and depth.element_size() == 4
+        assert ns.is_cuda and ns.is_contiguous() and ns.numel() == n and ns.element_size() == 4
+        spp_max = spp if spp_max is None else spp_max
+        sptr = C.c_void_p(stream) if stream else None
+        _check(lib().qa_render_strips_device(self._h, x0, y0, x1, y1, first_strip, strip_step, spp, spp_max,
+                                             max_bounce, seed, QA_RENDER_STATS if stats else 0, rgb.data_ptr(),
+                                             depth.data_ptr(), ns.data_ptr(), sptr))
 
     def synchronize(self):
         _check(lib().qa_synchronize(self._h))

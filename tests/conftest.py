@@ -1,0 +1,46 @@
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The product libraries and the oracle are built in-tree by __graft_entry__.build(); build them
+    here when a fresh checkout runs the tests directly."""
+    from qaray_amd import hip, host
+    from oracle import binding as oracle
+    if not (os.path.exists(host.HOST_LIB_PATH) and os.path.exists(hip.HIP_LIB_PATH) and os.path.exists(oracle.LIB_PATH)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return z["rgb"], z["depth"], z["ns"], meta
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def golden_blob(meta):
+    from qaray_amd.host import load_scene_blob
+    return load_scene_blob(meta["scene"], size=(meta["width"], meta["height"]))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the REAL reference (oracle/_ref/ref_harness, built by
+oracle/Makefile from /root/reference).  Only runs in the dev container; the fixtures it writes are
+data (float32 radiance / depth / sample counts + cast counters) and travel with the repo.
+
+Every fixture records: scene file (under scenes/), image size, crop, spp range, max bounce, seed.
+The per-pixel RNG stream is include/qa_seed.h's qa_pixel_seed(seed, j*W+i).
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+SCENES = os.path.join(ROOT, "scenes")
+
+# name, scene, (W,H), crop or None, spp_min, spp_max, bounce
+CASES = [
+    ("c1_sphere_256x256_1spp", "example_project3_sphere.xml", (256, 256), None, 1, 1, 5),   # BASELINE config 0
+    ("c2_box_64x64_4spp", "example_project12_box.xml", (64, 64), None, 4, 4, 5),
+    ("c2_box_1080p_crop_8spp", "example_project12_box.xml", (1920, 1080), (900, 500, 948, 532), 8, 8, 5),
+    ("c2_box_1080p_edge_crop_64spp", "example_project12_box.xml", (1920, 1080), (1896, 1064, 1920, 1080), 64, 64, 5),
+    ("blinn_48x36_4spp", "example_project2_blinn.xml", (48, 36), None, 4, 4, 5),
+    ("box3_48x36_4spp", "example_project3_box.xml", (48, 36), None, 4, 4, 5),
+    ("project4_48x36_4spp", "example_project4.xml", (48, 36), None, 4, 4, 5),
+    ("glass_48x36_8spp", "trc_mtl_glass.xml", (48, 36), None, 8, 8, 5),
+    ("glossy_48x36_8spp", "trc_mtl_glossy.xml", (48, 36), None, 8, 8, 5),
+    ("coffee_48x36_4spp_bounce2", "trc_mtl_coffee.xml", (48, 36), None, 4, 4, 2),
+    ("sphere_adaptive_64x48_4to32spp", "example_project3_sphere.xml", (64, 48), None, 4, 32, 5),
+    ("textures_80x60_2spp", "custom_textures.xml", (80, 60), None, 2, 2, 5),
+    ("softshadow_dof_60x45_2spp", "custom_softshadow.xml", (60, 45), None, 2, 2, 5),
+]
+SEED = 0x51A7A7
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit(f"{HARNESS} missing: run `make -C oracle ref` in the dev container")
+    for name, scene, (w, h), crop, smin, smax, bounce in CASES:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "g")
+            cmd = [HARNESS, scene, "--size", str(w), str(h), "--spp-min", str(smin), "--spp-max", str(smax),
+                   "--bounce", str(bounce), "--seed", str(SEED), "--threads", "8", "--out", out]
+            if crop:
+                cmd += ["--crop"] + [str(c) for c in crop]
+            subprocess.run(cmd, cwd=SCENES, check=True, stdout=subprocess.DEVNULL)
+            meta = json.load(open(out + ".json"))
+            x0, y0, x1, y1 = meta["crop"]
+            ch, cw = y1 - y0, x1 - x0
+            rgb = np.fromfile(out + ".rgb.f32", np.float32).reshape(ch, cw, 3)
+            depth = np.fromfile(out + ".depth.f32", np.float32).reshape(ch, cw)
+            ns = np.fromfile(out + ".ns.u32", np.uint32).reshape(ch, cw)
+        info = dict(scene=scene, width=w, height=h, crop=[x0, y0, x1, y1], spp_min=smin, spp_max=smax,
+                    bounce=bounce, seed=SEED, samples=meta["samples"], casts_normal=meta["casts_normal"],
+                    casts_shadow=meta["casts_shadow"], producer="oracle/_ref/ref_harness (reference code)")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=rgb, depth=depth, ns=ns,
+                            meta=np.frombuffer(json.dumps(info).encode(), dtype=np.uint8))
+        print(f"{name}: {cw}x{ch} samples={meta['samples']} casts={meta['casts_normal']}+{meta['casts_shadow']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors, on a real MI355X.
+
+Tolerances (fp32 radiance, written here as the contract asks):
+  * sample counts, first-hit depth, ray-cast counters: EXACT (integer / bit-exact).
+  * radiance: scenes whose paths have at most one bounce after the camera hit and no lights
+    (Cornell box = BASELINE config[1]) are bit-identical to the reference.  Elsewhere the kernel sums
+    the reference's recursive radiance formula front-to-back (a throughput product instead of nested
+    multiplications) and uses fp64-rounded powf/expf instead of glibc's, which moves results by a
+    few ulp: per-image RMSE <= 1e-6 and max abs error <= 1e-4 (north_star: RMSE < 1e-4).
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, golden_blob, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 1e-6
+MAXABS_TOL = 1e-4
+SUPPORTED = ["c1_sphere_256x256_1spp", "c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp",
+             "blinn_48x36_4spp", "box3_48x36_4spp", "project4_48x36_4spp", "glass_48x36_8spp", "glossy_48x36_8spp",
+             "coffee_48x36_4spp_bounce2", "sphere_adaptive_64x48_4to32spp"]
+BIT_EXACT = ["c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from qaray_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_hip_matches_reference_goldens(ctx, name):
+    rgb, depth, ns, meta = load_golden(name)
+    ctx.upload_scene(golden_blob(meta))
+    ctx.reset_counters()
+    g_rgb, g_depth, g_ns = ctx.render_region(tuple(meta["crop"]), meta["spp_min"], max_bounce=meta["bounce"],
+                                             seed=meta["seed"], spp_max=meta["spp_max"])
+    cnt = ctx.counters()
+    assert np.array_equal(g_ns, ns)
+    assert np.array_equal(bits(g_depth), bits(depth))
+    assert cnt["samples"] == meta["samples"]
+    assert cnt["casts_normal"] == meta["casts_normal"] and cnt["casts_shadow"] == meta["casts_shadow"]
+    if name in BIT_EXACT:
+        assert np.array_equal(bits(g_rgb), bits(rgb))
+    else:
+        assert rmse(g_rgb, rgb) <= RMSE_TOL
+        assert float(np.abs(g_rgb - rgb).max()) <= MAXABS_TOL
+
+
+def test_hip_matches_oracle_with_traversal_counters(ctx):
+    """Same seeded inputs through both implementations, including BVH-node / triangle-test counts."""
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    blob = load_scene_blob("example_project12_box.xml", size=(160, 90))
+    ctx.upload_scene(blob)
+    ctx.reset_counters()
+    g = ctx.render_region((0, 0, 160, 90), 16, stats=True)
+    cnt = ctx.counters()
+    o_rgb, o_depth, o_ns, ocnt = oracle.render(blob, (0, 0, 160, 90), 16)
+    assert np.array_equal(bits(g[0]), bits(o_rgb)) and np.array_equal(bits(g[1]), bits(o_depth))
+    assert (cnt["bvh_nodes"], cnt["tri_tests"]) == (ocnt.bvh_nodes, ocnt.tri_tests)
+    assert cnt["pixels"] == 160 * 90
+
+
+def test_partition_invariance_and_determinism_full_size(ctx):
+    """Properties at BASELINE's full frame size (1920x1080): a region rendered alone, as part of a
+    bigger region, or as round-robin strips gives the same bits; two runs give the same bits."""
+    import torch
+    from qaray_amd import distributed as qd, hip
+    from qaray_amd.host import load_scene_blob
+    W, H, spp = 1920, 1080, 4
+    ctx.upload_scene(load_scene_blob("example_project12_box.xml", size=(W, H)))
+    full = ctx.render_region((0, 0, W, H), spp)[0]
+    again = ctx.render_region((0, 0, W, H), spp)[0]
+    assert np.array_equal(bits(full), bits(again))
+    crop = ctx.render_region((701, 333, 1222, 801), spp)[0]
+    assert np.array_equal(bits(crop), bits(full[333:801, 701:1222]))
+    dev = torch.device("cuda", 0)
+    world = 3
+    parts = []
+    for r in range(world):
+        n = hip.strip_count(0, H, r, world) * 8
+        rgb = torch.zeros((n, W, 3), dtype=torch.float32, device=dev)
+        d = torch.zeros((n, W), dtype=torch.float32, device=dev)
+        ns = torch.zeros((n, W), dtype=torch.int32, device=dev)
+        ctx.render_strips_device((0, 0, W, H), r, world, spp, rgb, d, ns)
+        ctx.synchronize()
+        parts.append(rgb.cpu().numpy())
+    asm = np.zeros((H, W, 3), np.float32)
+    for r in range(world):
+        qd.place_strips(asm, parts[r], H, world, r)
+    assert np.array_equal(bits(asm), bits(full))
+    # a different seed changes the image; the first-hit geometry does not depend on the seed
+    other = ctx.render_region((0, 0, W, H), spp, seed=12345)
+    assert not np.array_equal(bits(other[0]), bits(full))
+    # energy sanity: Cornell box radiance is finite and non-negative
+    assert np.isfinite(full).all() and (full >= 0).all()
+
+
+def test_device_blob_upload_equals_host_upload(ctx):
+    import torch
+    from qaray_amd.host import load_scene_blob
+    blob = load_scene_blob("example_project3_sphere.xml", size=(96, 64))
+    ctx.upload_scene(blob)
+    a = ctx.render_region((0, 0, 96, 64), 2)[0]
+    ctx.upload_scene_device(torch.from_numpy(blob).cuda())
+    b = ctx.render_region((0, 0, 96, 64), 2)[0]
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_stop_flag_skips_pixels_and_error_codes(ctx):
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    fresh = hip.Context(0)
+    with pytest.raises(hip.HipError) as e:
+        fresh.render_region((0, 0, 8, 8), 1)
+    assert e.value.code == -5  # QA_ENOSCENE
+    blob = load_scene_blob("example_project12_box.xml", size=(64, 64))
+    fresh.upload_scene(blob)
+    with pytest.raises(hip.HipError) as e:
+        fresh.render_region((0, 0, 65, 64), 1)
+    assert e.value.code == -1
+    with pytest.raises(hip.HipError) as e:
+        fresh.upload_scene(blob[:100])
+    assert e.value.code == -1
+    fresh.upload_scene(blob)
+    fresh.request_stop()               # tasking::signal_stop before the render: nothing is rendered
+    rgb, depth, ns = fresh.render_region((0, 0, 64, 64), 4)
+    assert (ns == 0).all()
+    fresh.clear_stop()
+    rgb, depth, ns = fresh.render_region((0, 0, 64, 64), 4)
+    assert (ns == 4).all()
+    # features the HIP path does not implement yet are refused loudly, never silently approximated
+    for scene in ("custom_textures.xml", "custom_softshadow.xml"):
+        with pytest.raises(hip.HipError) as e:
+            fresh.upload_scene(load_scene_blob(scene))
+        assert e.value.code == -6  # QA_EUNSUPPORTED
+    fresh.close()
+
+
+def test_device_sincos_equals_host_libm(ctx):
+    """The device sinf/cosf restate glibc's algorithm; on [0, 2*pi] they return glibc's bits."""
+    from qaray_amd import hip
+    import ctypes as C
+    x = np.concatenate([np.linspace(0, 2 * np.pi, 200001, dtype=np.float32),
+                        np.random.default_rng(1).random(300000, dtype=np.float32) * np.float32(6.2831855)])
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    L = hip.lib()
+    L.qa_test_sincosf_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.qa_test_sincosf_device(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data) == 0
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = C.c_float
+    libm.sinf.argtypes = [C.c_float]
+    libm.cosf.restype = C.c_float
+    libm.cosf.argtypes = [C.c_float]
+    idx = np.random.default_rng(2).choice(x.size, 20000, replace=False)
+    hs = np.array([libm.sinf(float(v)) for v in x[idx]], np.float32)
+    hc = np.array([libm.cosf(float(v)) for v in x[idx]], np.float32)
+    assert np.array_equal(bits(s[idx]), bits(hs)) and np.array_equal(bits(c[idx]), bits(hc))

@@ -1,0 +1,218 @@
+"""Host C++ layer (libqaray_host.so): XML/OBJ/MTL/PNG/PPM loaders, scene graph, BVH builder and the
+flattener, checked against what the reference's own loader built (tests/golden/scene_dump_*.json,
+written by oracle/_ref/ref_harness --dump-scene: node transforms, camera frame, mesh arrays, faces
+after the material sort, cy::BVH nodes and leaf elements; floats are stored as bit patterns)."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from qaray_amd.host import FrameBuffer, HostScene, load_scene_blob, SCENES_DIR
+
+# ---- minimal python reader of include/qa_flat_scene.h ------------------------------------------
+HDR = struct.Struct("<IIQ15f3f f II I 4f 4f 8I 7Q 5Q")
+
+
+def parse_blob(blob):
+    b = blob.tobytes()
+    f = struct.unpack_from("<IIQ", b, 0)
+    assert f[0] == 0x31534151 and f[1] == 1 and f[2] == len(b)
+    off = 16
+    cam = np.frombuffer(b, np.float32, 18, off); off += 72
+    dof = struct.unpack_from("<f", b, off)[0]; off += 4
+    width, height, _ = struct.unpack_from("<III", b, off); off += 12
+    off += 32  # background, environment
+    counts = struct.unpack_from("<8I", b, off); off += 32
+    offs = struct.unpack_from("<7Q", b, off)
+    names = ["instances", "meshes", "mtlsets", "materials", "lights", "texmaps", "textures"]
+    out = dict(cam=cam, dof=dof, width=width, height=height, counts=dict(zip(names, counts[:7])), offs=dict(zip(names, offs)))
+    inst = []
+    for k in range(counts[0]):
+        o = offs[0] + k * 112
+        fl = np.frombuffer(b, np.uint32, 21, o)
+        ints = struct.unpack_from("<7i", b, o + 84)
+        inst.append(dict(tm=fl[0:9], itm=fl[9:18], pos=fl[18:21], obj_type=ints[0], mesh=ints[1], mtlset=ints[2],
+                         parent=ints[3], subtree_end=ints[4], depth=ints[5]))
+    out["inst"] = inst
+    meshes = []
+    for k in range(counts[1]):
+        o = offs[1] + k * 96
+        bb = np.frombuffer(b, np.uint32, 6, o)
+        nf, nv, nn, nt, nb, _ = struct.unpack_from("<6I", b, o + 24)
+        mo = struct.unpack_from("<6Q", b, o + 48)
+        meshes.append(dict(bb=bb, nf=nf, nv=nv, nn=nn, nt=nt, nb=nb,
+                           nodes=np.frombuffer(b, np.uint32, nb * 7, mo[0]).reshape(nb, 7),
+                           elements=np.frombuffer(b, np.uint32, nf, mo[1]),
+                           faces=np.frombuffer(b, np.int32, nf * 10, mo[2]).reshape(nf, 10),
+                           v=np.frombuffer(b, np.uint32, nv * 3, mo[3]).reshape(nv, 3),
+                           vn=np.frombuffer(b, np.uint32, nn * 3, mo[4]).reshape(nn, 3),
+                           vt=np.frombuffer(b, np.uint32, nt * 2, mo[5]).reshape(nt, 2)))
+    out["meshes"] = meshes
+    return out
+
+
+def flatten_ref_nodes(node, out, parent=-1, depth=0):
+    me = len(out)
+    out.append(dict(node=node, parent=parent, depth=depth))
+    for c in node["children"]:
+        flatten_ref_nodes(c, out, me, depth + 1)
+    out[me]["subtree_end"] = len(out)
+
+
+@pytest.mark.parametrize("name", ["example_project12_box", "custom_textures", "custom_softshadow", "trc_scene_xmas"])
+def test_flattened_scene_equals_reference_loader(name):
+    ref = json.load(open(os.path.join(GOLDEN, f"scene_dump_{name}.json")))
+    if name == "trc_scene_xmas":
+        # its OBJ assets are not shipped with the reference: nodes/lights/camera are still comparable
+        pass
+    blob = load_scene_blob(name + ".xml")
+    s = parse_blob(blob)
+    assert (s["width"], s["height"]) == (ref["width"], ref["height"])
+    assert np.array_equal(s["cam"][:15].view(np.uint32), np.array(ref["camera_frame"][:15], np.uint32))
+    nodes = []
+    flatten_ref_nodes(ref["root"], nodes)
+    assert len(nodes) == len(s["inst"])
+    types = {"none": 0, "sphere": 1, "plane": 2, "obj": 3}
+    for mine, r in zip(s["inst"], nodes):
+        n = r["node"]
+        assert np.array_equal(mine["tm"], np.array(n["tm"], np.uint32)), n["name"]
+        assert np.array_equal(mine["itm"], np.array(n["itm"], np.uint32)), n["name"]
+        assert np.array_equal(mine["pos"], np.array(n["pos"], np.uint32)), n["name"]
+        assert mine["parent"] == r["parent"] and mine["depth"] == r["depth"] and mine["subtree_end"] == r["subtree_end"]
+        if n["type"] == "obj" and n["mesh"] < 0:
+            assert mine["obj_type"] == 0  # OBJ failed to load on both sides -> object-less node
+        else:
+            assert mine["obj_type"] == types[n["type"]]
+            assert mine["mesh"] == n["mesh"]
+        assert (mine["mtlset"] >= 0) == (n["material"] != "")
+    assert s["counts"]["lights"] == ref["num_lights"]
+    assert len(s["meshes"]) == len(ref["meshes"])
+    for mine, r in zip(s["meshes"], ref["meshes"]):
+        assert (mine["nf"], mine["nv"], mine["nn"], mine["nt"]) == (r["nf"], r["nv"], r["nvn"], r["nvt"])
+        assert np.array_equal(mine["bb"], np.array(r["bmin"] + r["bmax"], np.uint32))
+        assert np.array_equal(mine["v"], np.array(r["v"], np.uint32).reshape(-1, 3))
+        assert np.array_equal(mine["vn"], np.array(r["vn"], np.uint32).reshape(-1, 3))
+        if r["nvt"]:
+            assert np.array_equal(mine["vt"], np.array(r["vt"], np.uint32).reshape(-1, 2))
+        assert np.array_equal(mine["faces"], np.array(r["faces"], np.int32))
+        # BVH: node i of the dump is node i+1 (root = 1)
+        assert mine["nb"] == len(r["bvh_nodes"]) + 1
+        for i, rn in enumerate(r["bvh_nodes"]):
+            node = mine["nodes"][i + 1]
+            assert np.array_equal(node[:6], np.array(rn[:6], np.uint32))
+            data = int(node[6])
+            if rn[6] == 1:
+                assert data & 0x80000000
+                cnt = ((data >> 28) & 7) + 1
+                first = data & 0x0FFFFFFF
+                assert cnt == rn[7]
+                assert list(mine["elements"][first:first + cnt]) == rn[8:8 + cnt]
+            else:
+                assert not (data & 0x80000000) and (data & 0x7FFFFFFF) == rn[7]
+
+
+def test_bvh_invariants():
+    s = parse_blob(load_scene_blob("example_project12_box.xml"))
+    m = s["meshes"][0]
+    assert sorted(m["elements"].tolist()) == list(range(m["nf"]))
+    seen = np.zeros(m["nf"], bool)
+    stack = [1]
+    while stack:
+        i = stack.pop()
+        data = int(m["nodes"][i][6])
+        box = m["nodes"][i][:6].view(np.float32)
+        if data & 0x80000000:
+            cnt, first = ((data >> 28) & 7) + 1, data & 0x0FFFFFFF
+            assert cnt <= 8  # <=4 by the split rule, up to 8 when no axis separates the centres (cyBVH.h:331-338)
+            for f in m["elements"][first:first + cnt]:
+                assert not seen[f]
+                seen[f] = True
+                pts = m["v"].view(np.float32)[m["faces"][f][:3]]
+                assert np.all(pts >= box[:3] - 0) and np.all(pts <= box[3:])
+        else:
+            c = data & 0x7FFFFFFF
+            assert c % 2 == 0
+            stack += [c, c + 1]
+    assert seen.all()
+
+
+def test_xml_errors_and_missing_assets(tmp_path):
+    from qaray_amd.host import HostError
+    with pytest.raises(HostError):
+        HostScene(str(tmp_path / "nope.xml"))
+    bad = tmp_path / "bad.xml"
+    bad.write_text("<xml><scene><object></scene></xml>")
+    with pytest.raises(HostError):
+        HostScene(str(bad))
+    nocam = tmp_path / "nocam.xml"
+    nocam.write_text("<xml><scene/></xml>")
+    with pytest.raises(HostError):
+        HostScene(str(nocam))
+    # a scene whose OBJ is missing still loads (the reference prints an error and continues)
+    ok = tmp_path / "missing_obj.xml"
+    ok.write_text('<xml><scene><object type="obj" name="nothere.obj"/><!-- c --></scene>'
+                  '<camera><width value="8"/><height value="4"/></camera></xml>')
+    s = parse_blob(HostScene(str(ok)).flatten())
+    assert (s["width"], s["height"]) == (8, 4) and s["inst"][1]["obj_type"] == 0
+
+
+def test_camera_size_override():
+    sc = HostScene(os.path.join(SCENES_DIR, "example_project12_box.xml"))
+    assert sc.size == (608, 600)
+    sc.set_size(1920, 1080)
+    assert parse_blob(sc.flatten())["width"] == 1920
+
+
+def test_png_codec_roundtrip_and_zlib_interop(tmp_path):
+    import zlib
+    lib = C.CDLL(os.path.join(ROOT, "qaray_amd", "lib", "libqaray_host.so"))
+    fb = FrameBuffer(37, 21)
+    rng = np.random.default_rng(3)
+    rgb = rng.random((21, 37, 3), dtype=np.float32)
+    fb.deposit(0, 0, 37, 21, rgb, np.ones((21, 37), np.float32), np.full((21, 37), 4, np.uint32), 4, use_srgb=False)
+    p = str(tmp_path / "out.png")
+    fb.save_image(p)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    # decode with python's zlib: our encoder emits stored blocks that any inflater accepts
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n = struct.unpack(">I", raw[pos:pos + 4])[0]
+        t = raw[pos + 4:pos + 8]
+        d = raw[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + d) & 0xFFFFFFFF == struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IDAT":
+            idat += d
+        pos += 12 + n
+    rows = zlib.decompress(idat)
+    img = np.frombuffer(rows, np.uint8).reshape(21, 37 * 3 + 1)[:, 1:].reshape(21, 37, 3)
+    assert np.array_equal(img, fb.pixels)
+    expect = np.round(np.clip(rgb, 0, 1) * 255).astype(np.uint8)
+    assert np.abs(img.astype(int) - expect.astype(int)).max() <= 0  # roundf == np.round away from .5 ties: none in random data
+
+
+def test_framebuffer_postprocess_matches_reference_formula():
+    # src/renderers/renderer.cpp:34-39,347-365: sRGB, clamp, roundf*255, sample-count byte, mask
+    fb = FrameBuffer(4, 2)
+    rgb = np.array([[[0.0, 0.001, 0.0031308], [0.2, 0.5, 1.0], [1.5, -0.2, 0.75], [0.01, 0.02, 0.04]]] * 2, np.float32)
+    depth = np.arange(8, dtype=np.float32).reshape(2, 4)
+    ns = np.array([[4, 8, 16, 3]] * 2, np.uint32)
+    fb.deposit(0, 0, 4, 2, rgb, depth, ns, 16, use_srgb=True)
+
+    def srgb(c):
+        c = np.float32(c)
+        return np.float32(12.92) * c if c < np.float32(0.0031308) else np.float32(1.055) * np.float32(c ** np.float32(1 / 2.4)) - np.float32(0.055)
+    exp = np.zeros((2, 4, 3), np.uint8)
+    for j in range(2):
+        for i in range(4):
+            for k in range(3):
+                v = min(1.0, max(0.0, float(srgb(rgb[j, i, k]))))
+                exp[j, i, k] = int(np.floor(v * 255 + 0.5))
+    assert np.abs(fb.pixels.astype(int) - exp.astype(int)).max() <= 1
+    assert np.array_equal(fb.zbuffer, depth)
+    assert np.array_equal(fb.sample_count, (255.0 * ns / 16.0).astype(np.uint8))
+    assert fb.mask.all() and fb.num_rendered_pixels == 8

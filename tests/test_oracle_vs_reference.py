@@ -1,0 +1,61 @@
+"""The oracle (oracle/qa_oracle.c) against golden vectors produced by the REAL reference
+(tests/golden/make_goldens.py -> oracle/_ref/ref_harness).  Bit-exact: the restatement performs the
+reference's fp32 operations in the reference's order and calls the same glibc entry points.
+This also pins the host loader/flattener, because the goldens start from the XML + OBJ files."""
+import numpy as np
+import pytest
+
+from conftest import bits, golden_blob, golden_names, load_golden
+from oracle import binding as oracle
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_bit_for_bit(name):
+    rgb, depth, ns, meta = load_golden(name)
+    blob = golden_blob(meta)
+    o_rgb, o_depth, o_ns, cnt = oracle.render(blob, tuple(meta["crop"]), meta["spp_min"], max_bounce=meta["bounce"],
+                                              seed=meta["seed"], spp_max=meta["spp_max"])
+    assert np.array_equal(o_ns, ns)
+    assert np.array_equal(bits(o_depth), bits(depth))
+    assert np.array_equal(bits(o_rgb), bits(rgb))
+    # the reference's own cast counts (linker --wrap on Scene::TraceNode*)
+    assert cnt.samples == meta["samples"]
+    assert cnt.casts_normal == meta["casts_normal"]
+    assert cnt.casts_shadow == meta["casts_shadow"]
+
+
+def test_oracle_thread_count_does_not_change_pixels():
+    rgb, depth, ns, meta = load_golden("glass_48x36_8spp")
+    blob = golden_blob(meta)
+    a = oracle.render(blob, tuple(meta["crop"]), 8, threads=1)[0]
+    b = oracle.render(blob, tuple(meta["crop"]), 8, threads=4)[0]
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(rgb))
+
+
+def test_oracle_crop_equals_full_frame_block():
+    _, _, _, meta = load_golden("c2_box_64x64_4spp")
+    blob = golden_blob(meta)
+    full = oracle.render(blob, (0, 0, 64, 64), 4)[0]
+    crop = oracle.render(blob, (17, 9, 40, 33), 4)[0]
+    assert np.array_equal(bits(crop), bits(full[9:33, 17:40]))
+
+
+def test_halton_and_rng_known_answers():
+    # Halton radical inverse: base 11 / 13 of small indices are exact fractions
+    assert oracle.halton(0, 11) == 0.0
+    assert abs(oracle.halton(1, 11) - 1 / 11) < 1e-7
+    assert abs(oracle.halton(11, 11) - 1 / 121) < 1e-7
+    assert abs(oracle.halton(14, 13) - (1 / 13 + 1 / 169)) < 1e-7
+    # xorshift32 (13,17,5) from state 1: Marsaglia's sequence, scaled by 2^-32
+    s = oracle.rng_stream(0, 0, 4)
+    assert np.all((s > 0) & (s <= 1))
+    x = np.uint32(1)
+    from qaray_amd.seed import pixel_seed
+    x = np.uint32(pixel_seed(0, 0))
+    exp = []
+    for _ in range(4):
+        x ^= np.uint32((int(x) << 13) & 0xFFFFFFFF)
+        x ^= np.uint32(int(x) >> 17)
+        x ^= np.uint32((int(x) << 5) & 0xFFFFFFFF)
+        exp.append(np.float32(np.float32(x) / np.float32(4294967296.0)))
+    assert np.array_equal(s, np.array(exp, np.float32))
