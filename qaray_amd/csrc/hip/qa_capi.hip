@@ -51,7 +51,12 @@ struct qa_ctx {
   std::vector<EventPair> pending, freeEvents;
   double totalMs = 0;
   uint64_t launches = 0;
-  int blocksPerCU = 4, threads = QA_BLOCK;
+  int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
+  void (*kernel)(const DScene, const RenderParams) = nullptr;
+  void (*kernelStats)(const DScene, const RenderParams) = nullptr;
+  bool resident = false;
+  uint32_t stackDepth = 32;
+  size_t ldsBytes = 0;
 };
 
 static void FreeScene(qa_ctx *c)
@@ -103,6 +108,34 @@ static int EnsureHalton(qa_ctx *c, int count)
   return QA_OK;
 }
 
+typedef void (*KernelFn)(const DScene, const RenderParams);
+static const size_t kMaxLdsPerBlock = 64 * 1024;      // dynamic LDS a workgroup may ask for without opt-in
+static const size_t kResidentLdsBudget = 40 * 1024;   // image + stacks: keeps 4 workgroups per CU (160 KB LDS)
+
+static KernelFn PickKernel(bool resident, bool lights, bool stats)
+{
+  if (resident) {
+    if (lights) return stats ? (KernelFn) qa_integrate<true, true, true> : (KernelFn) qa_integrate<true, true, false>;
+    return stats ? (KernelFn) qa_integrate<true, false, true> : (KernelFn) qa_integrate<true, false, false>;
+  }
+  if (lights) return stats ? (KernelFn) qa_integrate<false, true, true> : (KernelFn) qa_integrate<false, true, false>;
+  return stats ? (KernelFn) qa_integrate<false, false, true> : (KernelFn) qa_integrate<false, false, false>;
+}
+
+// Choose the kernel variant for the uploaded scene and size the persistent grid to what is
+// resident at once (VGPR / LDS-limited workgroups per CU x CUs).
+static int SelectKernel(qa_ctx *c)
+{
+  const bool lights = c->ds.num_lights > 0;
+  c->kernel = PickKernel(c->resident, lights, false);
+  c->kernelStats = PickKernel(c->resident, lights, true);
+  int resident = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
+    resident = 2;
+  c->blocksPerCUAuto = resident > 8 ? 8 : resident;
+  return QA_OK;
+}
+
 // Validate the blob and build the device tables.
 static int PrepareScene(qa_ctx *c)
 {
@@ -140,11 +173,15 @@ static int PrepareScene(qa_ctx *c)
   for (uint32_t i = 0; i < h->num_lights; ++i)
     if ((light[i].type == QA_LIGHT_POINT || light[i].type == QA_LIGHT_SPOT) && light[i].size > 0.01f)
       return Fail(QA_EUNSUPPORTED, "area lights (size > 0.01) need post-order RNG replay: not implemented on the HIP path yet");
-  if (h->num_texmaps > 0)
+  if (h->num_texmaps > 0 || h->background.texmap >= 0 || h->environment.texmap >= 0)
     return Fail(QA_EUNSUPPORTED, "textured colours are not implemented on the HIP path yet");
 
   // ---- derived per-mesh arrays --------------------------------------------------------------
   std::vector<DMesh> dmeshes(h->num_meshes);
+  std::vector<std::vector<DNode>> allNodes(h->num_meshes);
+  std::vector<std::vector<DTri>> allTris(h->num_meshes);
+  std::vector<std::vector<DTriShade>> allShade(h->num_meshes);
+  uint32_t stackNeedMax = 1;
   for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
     const qa_mesh &m = mesh[mi];
     if (!inside(m.off_bvh_nodes, (uint64_t) m.num_bvh_nodes * sizeof(qa_bvh_node)) ||
@@ -157,22 +194,43 @@ static int PrepareScene(qa_ctx *c)
     const qa_face *faces = QA_BLOB_PTR(qa_face, blob, m.off_faces);
     const float *V = QA_BLOB_PTR(float, blob, m.off_vertices);
     const float *VN = QA_BLOB_PTR(float, blob, m.off_normals);
-    const float *VT = QA_BLOB_PTR(float, blob, m.off_texcoords);
-    std::vector<DNode> dn(m.num_bvh_nodes);
+    std::vector<DNode> &dn = allNodes[mi];
+    dn.resize(m.num_bvh_nodes + (m.num_bvh_nodes & 1));  // even count: sibling pairs are 64-byte units
+    memset(dn.data(), 0, dn.size() * sizeof(DNode));
     for (uint32_t i = 0; i < m.num_bvh_nodes; ++i) {
       memcpy(dn[i].box, nodes[i].box, sizeof(dn[i].box));
       dn[i].data = nodes[i].data;
-      dn[i].pad = 0;
-      if (i >= 1 && !(nodes[i].data & QA_BVH_LEAF_BIT) && m.num_faces > 0) {
-        const uint32_t c = nodes[i].data & QA_BVH_CHILD_MASK;
-        if (c + 1 >= m.num_bvh_nodes) return Fail(QA_EINVAL, "BVH child index out of range");
-      } else if (i >= 1 && m.num_faces > 0) {
-        const uint32_t cnt = ((nodes[i].data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
-        if ((nodes[i].data & QA_BVH_OFFSET_MASK) + cnt > m.num_faces) return Fail(QA_EINVAL, "BVH leaf range out of range");
+      if (i >= 1 && m.num_faces > 0) {
+        if (!(nodes[i].data & QA_BVH_LEAF_BIT)) {
+          const uint32_t ch = nodes[i].data & QA_BVH_CHILD_MASK;
+          if (ch + 1 >= m.num_bvh_nodes || ch <= i || (ch & 1)) return Fail(QA_EINVAL, "BVH child index out of range");
+        } else {
+          const uint32_t cnt = ((nodes[i].data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+          if ((nodes[i].data & QA_BVH_OFFSET_MASK) + cnt > m.num_faces) return Fail(QA_EINVAL, "BVH leaf range out of range");
+          if (nodes[i].data == QA_DONE) return Fail(QA_EUNSUPPORTED, "leaf word collides with the traversal sentinel");
+        }
       }
     }
-    std::vector<DTri> dt(m.num_faces);
-    std::vector<DTriShade> dsh(m.num_faces);
+    // deepest stack the traversal can need = BVH depth (one pending sibling per level); children
+    // always have larger indices than their parent, so a forward sweep computes node depths
+    uint32_t stackNeed = 1;
+    if (m.num_faces > 0 && m.num_bvh_nodes > 1) {
+      std::vector<uint32_t> level(m.num_bvh_nodes, 0);
+      level[1] = 1;
+      for (uint32_t i = 1; i < m.num_bvh_nodes; ++i) {
+        if (level[i] == 0) continue;
+        if (!(nodes[i].data & QA_BVH_LEAF_BIT)) {
+          const uint32_t ch = nodes[i].data & QA_BVH_CHILD_MASK;
+          level[ch] = level[ch + 1] = level[i] + 1;
+          if (level[i] + 1 > stackNeed) stackNeed = level[i] + 1;
+        }
+      }
+    }
+    if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
+    std::vector<DTri> &dt = allTris[mi];
+    std::vector<DTriShade> &dsh = allShade[mi];
+    dt.resize(m.num_faces);
+    dsh.resize(m.num_faces);
     for (uint32_t e = 0; e < m.num_faces; ++e) {
       const uint32_t fid = elements[e];
       if (fid >= m.num_faces) return Fail(QA_EINVAL, "BVH element out of range");
@@ -194,51 +252,93 @@ static int PrepareScene(qa_ctx *c)
       DTri &t = dt[e];
       t.N[0] = N.x; t.N[1] = N.y; t.N[2] = N.z;
       t.A[0] = A.x; t.A[1] = A.y; t.A[2] = A.z;
-      t.au = U(A); t.av = W(A); t.bu = U(B); t.bv = W(B); t.cu = U(C); t.cv = W(C);
+      t.bu = U(B); t.bv = W(B); t.cu = U(C); t.cv = W(C);
       // TriangleArea(axis, A, B, C) (objects.cpp:30-41)
-      const float area = (t.bu - t.au) * (t.cv - t.av) - (t.cu - t.au) * (t.bv - t.av);
+      const float area = (t.bu - U(A)) * (t.cv - W(A)) - (t.cu - U(A)) * (t.bv - W(A));
       t.s = 1.f / area;
       t.axis = axis;
-      t.face = fid;
-      t.pad = 0;
       DTriShade &s = dsh[e];
       memcpy(s.n0, VN + 3 * f.vn[0], 12);
       memcpy(s.n1, VN + 3 * f.vn[1], 12);
       memcpy(s.n2, VN + 3 * f.vn[2], 12);
-      s.hasVT = (f.vt[0] >= 0 && f.vt[1] >= 0 && f.vt[2] >= 0) ? 1 : 0;
-      memset(s.t0, 0, 24);
-      if (s.hasVT) {
-        for (int k = 0; k < 3; ++k) if ((uint32_t) f.vt[k] >= m.num_texcoords) return Fail(QA_EINVAL, "texcoord index out of range");
-        memcpy(s.t0, VT + 2 * f.vt[0], 8);
-        memcpy(s.t1, VT + 2 * f.vt[1], 8);
-        memcpy(s.t2, VT + 2 * f.vt[2], 8);
-      }
       s.mtl = f.mtl;
+      s.face = fid;
+      s.pad = 0;
     }
     DMesh &dm = dmeshes[mi];
+    memset(&dm, 0, sizeof(dm));
     memcpy(dm.bmin, m.bmin, 12);
     memcpy(dm.bmax, m.bmax, 12);
     dm.num_faces = m.num_faces;
     dm.num_nodes = m.num_bvh_nodes;
-    dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : 0;
-    dm.pad = 0;
+    dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
+    dm.stackNeed = stackNeed;
     int rc;
     if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, dt, &dm.tris)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, dsh, &dm.shade)) != QA_OK) return rc;
   }
 
+  // ---- material table (plain colours) -----------------------------------------------------------
+  const qa_material *mats = QA_BLOB_PTR(qa_material, blob, h->off_materials);
+  std::vector<DMaterial> dmat(h->num_materials);
+  for (uint32_t i = 0; i < h->num_materials; ++i) {
+    const qa_material &m = mats[i];
+    DMaterial &d = dmat[i];
+    memcpy(d.diffuse, m.diffuse.color, 12);       d.kill = m.kill;
+    memcpy(d.specular, m.specular.color, 12);     d.gloss_spec = m.gloss_spec;
+    memcpy(d.emission, m.emission.color, 12);     d.ior = m.ior;
+    memcpy(d.reflection, m.reflection.color, 12); d.gloss_refl = m.gloss_refl;
+    memcpy(d.refraction, m.refraction.color, 12); d.gloss_refr = m.gloss_refr;
+    memcpy(d.absorption, m.absorption, 12);
+    d.flags = 0;
+    for (int k = 0; k < 3; ++k) {
+      if (m.reflection.color[k] != 0.f || m.refraction.color[k] != 0.f) d.flags |= QA_MTL_SPECULAR_LOBES;
+      if (m.specular.color[k] != 0.f) d.flags |= QA_MTL_HAS_SPECULAR;
+    }
+  }
+
+  // ---- resident image: [nodes | tris | shade] per mesh, then materials, in 16-byte units --------
+  std::vector<uint4> image;
+  auto append = [&](const void *p, size_t bytes) {
+    const uint32_t off = (uint32_t) image.size();
+    const size_t n = (bytes + 15) / 16;
+    image.resize(image.size() + n, uint4{0, 0, 0, 0});
+    if (bytes) memcpy(image.data() + off, p, bytes);
+    return off;
+  };
+  for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
+    while (image.size() % 4) image.push_back(uint4{0, 0, 0, 0});  // node pairs on 64-byte boundaries
+    dmeshes[mi].resNodes = append(allNodes[mi].data(), allNodes[mi].size() * sizeof(DNode));
+    dmeshes[mi].resTris = append(allTris[mi].data(), allTris[mi].size() * sizeof(DTri));
+    dmeshes[mi].resShade = append(allShade[mi].data(), allShade[mi].size() * sizeof(DTriShade));
+  }
+  const uint32_t resMaterials = append(dmat.data(), dmat.size() * sizeof(DMaterial));
+
   DScene &ds = c->ds;
   memset(&ds, 0, sizeof(ds));
   ds.blob = c->dBlob;
   ds.inst = QA_BLOB_PTR(qa_instance, c->dBlob, h->off_instances);
   ds.mtlset = QA_BLOB_PTR(qa_mtlset, c->dBlob, h->off_mtlsets);
-  ds.mtl = QA_BLOB_PTR(qa_material, c->dBlob, h->off_materials);
   ds.light = QA_BLOB_PTR(qa_light, c->dBlob, h->off_lights);
-  ds.texmap = QA_BLOB_PTR(qa_texmap, c->dBlob, h->off_texmaps);
-  ds.tex = QA_BLOB_PTR(qa_texture, c->dBlob, h->off_textures);
   int rc;
   if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
+  if ((rc = DeviceCopy(c, dmat, &ds.mtl)) != QA_OK) return rc;
+  ds.stackNeed = stackNeedMax;
+  c->stackDepth = stackNeedMax < 8 ? 8 : stackNeedMax;
+  // LDS budget per workgroup: resident image + stacks; small scenes stay entirely on the CU
+  const size_t stackBytes = (size_t) c->stackDepth * QA_BLOCK * sizeof(uint32_t);
+  const size_t imageBytes = image.size() * sizeof(uint4);
+  if (stackBytes > kMaxLdsPerBlock) return Fail(QA_EUNSUPPORTED, "BVH too deep for the LDS traversal stack");
+  c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget);
+  if (c->resident) {
+    const uint4 *dimg = nullptr;
+    if ((rc = DeviceCopy(c, image, &dimg)) != QA_OK) return rc;
+    ds.resident = dimg;
+    ds.residentVec4 = (uint32_t) image.size();
+    ds.resMaterials = resMaterials;
+  }
+  c->ldsBytes = stackBytes + (c->resident ? imageBytes : 0);
   memcpy(ds.cam.screenA, h->screenA, 12);
   memcpy(ds.cam.screenU, h->screenU, 12);
   memcpy(ds.cam.screenV, h->screenV, 12);
@@ -248,18 +348,13 @@ static int PrepareScene(qa_ctx *c)
   ds.cam.dof = h->dof;
   ds.cam.width = (int) h->width;
   ds.cam.height = (int) h->height;
-  ds.background = h->background;
-  ds.environment = h->environment;
+  memcpy(ds.background, h->background.color, 12);
+  memcpy(ds.environment, h->environment.color, 12);
   ds.num_inst = (int) h->num_instances;
   ds.num_lights = (int) h->num_lights;
+  ds.num_materials = (int) h->num_materials;
   c->haveScene = true;
-  return QA_OK;
-}
-
-template <bool STATS>
-static void Launch(qa_ctx *c, const RenderParams &rp, int blocks, hipStream_t s)
-{
-  hipLaunchKernelGGL(qa_integrate<STATS>, dim3((unsigned) blocks), dim3(QA_BLOCK), 0, s, c->ds, rp);
+  return SelectKernel(c);
 }
 
 static int OwnTileRows(int y0, int y1, int tile_row0, int tile_row_step)
@@ -305,7 +400,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
 
   const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ownRows;
   const long long needBlocks = ((long long) tiles * 64 + QA_BLOCK - 1) / QA_BLOCK;
-  long long blocks = (long long) c->numCUs * c->blocksPerCU;
+  long long blocks = (long long) c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : c->blocksPerCUAuto);
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
@@ -313,8 +408,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
   else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
   HIP_TRY(hipEventRecord(ev.a, s));
-  if (flags & QA_RENDER_STATS) Launch<true>(c, rp, (int) blocks, s);
-  else Launch<false>(c, rp, (int) blocks, s);
+  hipLaunchKernelGGL((flags & QA_RENDER_STATS) ? c->kernelStats : c->kernel, dim3((unsigned) blocks), dim3(QA_BLOCK),
+                     (unsigned) c->ldsBytes, s, c->ds, rp);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev.b, s));
   c->pending.push_back(ev);
@@ -401,10 +496,6 @@ int qa_ctx_create(int device_id, qa_ctx **out)
     return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
   }
   *c->hStop = 0;
-  // persistent grid = what is resident at once (VGPR/LDS-limited blocks per CU x CUs)
-  int resident = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, qa_integrate<false>, QA_BLOCK, 0) == hipSuccess && resident > 0)
-    c->blocksPerCU = resident > 8 ? 8 : resident;
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
@@ -588,7 +679,7 @@ int qa_set_launch_config(qa_ctx *c, int blocks_per_cu, int threads_per_block)
   if (!c) return Fail(QA_EINVAL, "null context");
   if (threads_per_block != 0 && threads_per_block != QA_BLOCK) return Fail(QA_EINVAL, "this build supports 256-thread workgroups only");
   if (blocks_per_cu < 0 || blocks_per_cu > 8) return Fail(QA_EINVAL, "blocks_per_cu must be in 0..8");
-  c->blocksPerCU = blocks_per_cu == 0 ? 4 : blocks_per_cu;
+  c->blocksPerCU = blocks_per_cu;
   return QA_OK;
 }
 

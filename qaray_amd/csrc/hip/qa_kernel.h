@@ -9,18 +9,21 @@
 // (src/lights/lights.cpp:39-144) and the xorshift32 sampler (src/samplers/Sampler_Marsaglia.cpp).
 //
 // Execution model (MI355X-first, not a translation of the CPU recursion):
-//  * Persistent threads.  The grid is sized to the chip (blocks_per_cu x 256 CUs); every LANE owns
-//    one pixel at a time and runs a small state machine: [fetch pixel] -> [start sample: camera
-//    ray] -> trace -> shade -> (next bounce | sample finished).  A finished path is replaced in
-//    the same loop iteration by the pixel's next sample, a finished pixel by a new pixel pulled
-//    from a global work counter with ONE atomic per wavefront (ballot + mbcnt prefix), so all 64
-//    lanes of a wave trace a ray in every iteration and no ray/hit queue ever goes through HBM:
-//    path state lives in VGPRs, the BVH stack in LDS.
-//  * The reference's recursion (Shade -> TraceNodeNormal -> Shade ...) is a chain, because
-//    exactly one of reflect / transmit / diffuse is followed per hit; it is unrolled into an
-//    iteration that carries a throughput.  Random numbers are drawn in the reference's order
-//    (select, lobe sample, then the deeper hits); lights that draw random numbers (area lights)
-//    are rejected at upload time because they would need a post-order replay.
+//  * Persistent threads.  The grid is sized to what is resident on the chip; every LANE owns one
+//    pixel at a time and runs a small state machine: [fetch pixel] -> [start sample: camera ray]
+//    -> trace -> shade -> (next bounce | sample finished).  A finished path is replaced in the same
+//    loop iteration by the pixel's next sample, a finished pixel by a new pixel pulled from a
+//    global work counter with ONE atomic per wavefront (ballot + mbcnt prefix), so all 64 lanes of
+//    a wave trace a ray in every iteration and no ray/hit queue ever goes through HBM: path state
+//    lives in VGPRs, the BVH stack and (for scenes that fit) the whole scene image in LDS.
+//  * The reference's recursion (Shade -> TraceNodeNormal -> Shade ...) is a chain, because exactly
+//    one of reflect / transmit / diffuse is followed per hit; it is unrolled into an iteration
+//    that carries a throughput.  Random numbers are drawn in the reference's order (select, lobe
+//    sample, then the deeper hits); lights that draw random numbers (area lights) are rejected at
+//    upload time because they would need a post-order replay.
+//  * BVH traversal is "while-while": a lane descends inner nodes until it holds a leaf, then the
+//    wave intersects leaves together; the per-lane visiting order is exactly the reference's
+//    (near child first, far child pushed), which decides ties between equal hit distances.
 //  * One xorshift32 stream per pixel (include/qa_seed.h); a pixel's samples are sequential by
 //    construction, pixels are the parallel dimension.
 #pragma once
@@ -33,19 +36,26 @@
 namespace qa {
 
 #define QA_BLOCK 256
-#define QA_STACK 32            /* LDS entries per lane; the reference uses 40 (src/objects/objects.cpp:331) */
 #define QA_BIAS 0.005f         /* src/objects/objects.cpp:19 */
-#define QA_DX 0.01f            /* DiffRay::dx, src/core/ray.cpp:31 */
+#define QA_DONE 0xFFFFFFFFu    /* traversal sentinel (has the leaf bit set, never a real node word) */
 
 struct Ray { f3 p, d; };
 
 struct Hit {
   float z;      // world-parametric distance (rays are not renormalised in node space)
-  f3 p, N;      // node-local until finishHit() maps them to world space
+  f3 p, N;      // node-local until traceClosest() maps them to world space
   int node;     // instance index, -1 = none
   int mtlID;
   bool front;
 };
+
+// Where the traversal reads the scene from: the LDS-resident image or global memory.
+template <bool RES>
+struct SceneMem {
+  const uint4 *img;  // LDS image (RES) - unused otherwise
+};
+
+__device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
 // ---------------------------------------------------------------------------------------------
 // RNG: Sampler_Marsaglia::xorshift32 (src/samplers/Sampler_Marsaglia.cpp:43-53)
@@ -100,6 +110,8 @@ __device__ __forceinline__ Ray toNode(const qa_instance &in, const Ray &r)
 // the ancestor chain top-down.  All lanes work on the same k, so the chain is wave-uniform.
 __device__ __forceinline__ Ray localRay(const DScene &sc, int k, const Ray &r0)
 {
+  const int depth = sc.inst[k].depth;
+  if (depth == 1) return toNode(sc.inst[k], r0);
   int chain[QA_MAX_NODE_DEPTH];
   int n = 0;
   for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = sc.inst[a].parent) chain[n++] = a;
@@ -179,10 +191,10 @@ __device__ __forceinline__ void slab(float d, float p0, float p1, float &t0, flo
   if (qabs(d) < 1e-7f) { t0 = -QA_BIGFLOAT; t1 = QA_BIGFLOAT; }
   else { t0 = qmin(p0, p1); t1 = qmax(p0, p1); }
 }
-__device__ __forceinline__ void boxEntryExit(const Ray &ray, f3 drcp, const float *box, float &entry, float &exit_)
+__device__ __forceinline__ void boxEntryExit(const Ray &ray, f3 drcp, f3 bmin, f3 bmax, float &entry, float &exit_)
 {
-  const f3 p0 = (-(ray.p - ld3(box))) * drcp;
-  const f3 p1 = (-(ray.p - ld3(box + 3))) * drcp;
+  const f3 p0 = (-(ray.p - bmin)) * drcp;
+  const f3 p1 = (-(ray.p - bmax)) * drcp;
   f3 t0, t1;
   slab(ray.d.x, p0.x, p1.x, t0.x, t1.x);
   slab(ray.d.y, p0.y, p1.y, t0.y, t1.y);
@@ -191,26 +203,33 @@ __device__ __forceinline__ void boxEntryExit(const Ray &ray, f3 drcp, const floa
   exit_ = qmin(t1.x, qmin(t1.y, t1.z));
 }
 
-// TriObj::IntersectTriangle (src/objects/objects.cpp:212-306) on a precomputed record.
-// TriangleArea(axis, P, Q, R) = (Q.u-P.u)*(R.v-P.v) - (R.u-P.u)*(Q.v-P.v) with (u,v) the two
-// coordinates kept after dropping `axis` (objects.cpp:30-41).
-template <bool STATS>
-__device__ __forceinline__ bool hitTriangle(const DTri &tr, const Ray &ray, Hit &h, float &ba, float &bb,
-                                            DCounters &cnt)
+// TriObj::IntersectTriangle (src/objects/objects.cpp:212-306) on a precomputed 48-byte record
+// (three 16-byte words q0..q2, see DTri).  TriangleArea(axis, P, Q, R) =
+// (Q.u-P.u)*(R.v-P.v) - (R.u-P.u)*(Q.v-P.v) with (u,v) the two coordinates kept after dropping
+// `axis` (objects.cpp:30-41).
+__device__ __forceinline__ bool hitTriangle(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, Hit &h,
+                                            float &ba, float &bb)
 {
-  if (STATS) cnt.tri_tests++;
-  const f3 N = ld3(tr.N);
+  const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
+  const f3 A = F3(asF(q0.w), asF(q1.x), asF(q1.y));
   const float dz = dot(ray.d, N);
   if (qabs(dz) < 1e-7f) return false;
-  const float pz = dot(ray.p - ld3(tr.A), N);
+  const float pz = dot(ray.p - A, N);
+  // t = -pz/dz <= 0 <= bias whenever pz and dz have the same sign or pz is zero: the reference
+  // rejects those after its division (objects.cpp:226-229); decide them without dividing.
+  if ((pz > 0 && dz > 0) || (pz < 0 && dz < 0) || pz == 0) return false;
   const float t = -pz / dz;
   if (t <= QA_BIAS) return false;
   if (h.z > t) {
+    const uint32_t axis = q2.w;
     const f3 p = ray.p + ray.d * t;
-    const float pu = (tr.axis == 0) ? p.y : p.x;
-    const float pv = (tr.axis == 2) ? p.y : p.z;
-    const float a = ((tr.bu - pu) * (tr.cv - pv) - (tr.cu - pu) * (tr.bv - pv)) * tr.s;
-    const float b = ((tr.cu - pu) * (tr.av - pv) - (tr.au - pu) * (tr.cv - pv)) * tr.s;
+    const float pu = (axis == 0) ? p.y : p.x;
+    const float pv = (axis == 2) ? p.y : p.z;
+    const float au = (axis == 0) ? A.y : A.x;
+    const float av = (axis == 2) ? A.y : A.z;
+    const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
+    const float a = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
+    const float b = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
     const float c = 1.f - a - b;
     if (a < 0 || b < 0 || c < 0) return false;
     h.z = t;
@@ -224,74 +243,83 @@ __device__ __forceinline__ bool hitTriangle(const DTri &tr, const Ray &ray, Hit 
 }
 
 // TriObj::IntersectRay + TraceBVHNode (src/objects/objects.cpp:310-420).  The traversal stack
-// holds the popped node's DATA word (leaf flag + range, or child index) instead of its id: the
-// word arrives together with the node's box when the parent tests its two children, so an inner
-// visit costs a single 64-byte read of the sibling pair.
-template <bool STATS>
-__device__ __forceinline__ bool hitMesh(const DMesh &m, const Ray &ray, Hit &h, int k, bool closest,
-                                        uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt)
+// holds node DATA words (leaf flag + range, or child index) instead of ids: the word arrives with
+// the node's box when the parent tests its two children, so an inner visit is a single 64-byte
+// read of the sibling pair.
+template <bool RES, bool STATS>
+__device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
+                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
   {
-    float box[6] = {m.bmin[0], m.bmin[1], m.bmin[2], m.bmax[0], m.bmax[1], m.bmax[2]};
     float entry, exit_;
-    boxEntryExit(ray, drcp, box, entry, exit_);
+    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, exit_);
     if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
   }
   if (m.num_faces == 0) return false;
+  const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
+  const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
   bool hasHit = false;
   int sp = 0;
   uint32_t bestTri = 0;
   float ba = 0, bb = 0;
-  stack[0] = m.rootData;
-  sp = 1;
-  while (sp != 0) {
-    const uint32_t data = stack[(--sp) * QA_BLOCK];
-    if (STATS) cnt.bvh_nodes++;
-    if (data & QA_BVH_LEAF_BIT) {
-      const uint32_t count = ((data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
-      const uint32_t first = data & QA_BVH_OFFSET_MASK;
-      for (uint32_t i = 0; i < count; ++i) {
-        if (hitTriangle<STATS>(m.tris[first + i], ray, h, ba, bb, cnt)) {
-          hasHit = true;
-          bestTri = first + i;
-          if (!closest) return true;
-        }
-      }
-    } else {
-      const uint32_t c0 = data & QA_BVH_CHILD_MASK;
-      const DNode &n0 = m.nodes[c0];
-      const DNode &n1 = m.nodes[c0 + 1];
+  uint32_t cur = m.rootData;
+  while (cur != QA_DONE) {
+    // ---- descend inner nodes until this lane holds a leaf (or runs out of work) --------------
+    while (!(cur & QA_BVH_LEAF_BIT)) {
+      if (STATS) cnt.bvh_nodes++;
+      const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
+      const uint4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
       float entry0, exit0, entry1, exit1;
-      boxEntryExit(ray, drcp, n0.box, entry0, exit0);
-      boxEntryExit(ray, drcp, n1.box, entry1, exit1);
+      boxEntryExit(ray, drcp, F3(asF(a0.x), asF(a0.y), asF(a0.z)), F3(asF(a0.w), asF(a1.x), asF(a1.y)), entry0, exit0);
+      boxEntryExit(ray, drcp, F3(asF(b0.x), asF(b0.y), asF(b0.z)), F3(asF(b0.w), asF(b1.x), asF(b1.y)), entry1, exit1);
       const float t_max = h.z;
       const bool hit0 = (entry0 < t_max && entry0 < exit0);
       const bool hit1 = (entry1 < t_max && entry1 < exit1);
+      const uint32_t d0 = a1.z, d1 = b1.z;
       if (hit0 && hit1) {
+        // the reference pushes the far child, then the near one, and pops the near one next
         const bool nearFirst = entry0 < entry1;
-        stack[(sp++) * QA_BLOCK] = nearFirst ? n1.data : n0.data;
-        stack[(sp++) * QA_BLOCK] = nearFirst ? n0.data : n1.data;
-      } else if (hit0) stack[(sp++) * QA_BLOCK] = n0.data;
-      else if (hit1) stack[(sp++) * QA_BLOCK] = n1.data;
-      if (sp > QA_STACK - 2) break;  // deeper than the reference's own stack allows
+        stack[(sp++) * QA_BLOCK] = nearFirst ? d1 : d0;
+        cur = nearFirst ? d0 : d1;
+      } else if (hit0) cur = d0;
+      else if (hit1) cur = d1;
+      else cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
     }
+    if (cur == QA_DONE) break;
+    // ---- leaf: its triangles in element order -----------------------------------------------
+    if (STATS) cnt.bvh_nodes++;
+    const uint32_t count = ((cur >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+    const uint32_t first = cur & QA_BVH_OFFSET_MASK;
+    for (uint32_t i = 0; i < count; ++i) {
+      if (STATS) cnt.tri_tests++;
+      const uint4 *t = tris + 3 * (size_t) (first + i);
+      if (hitTriangle(t[0], t[1], t[2], ray, h, ba, bb)) {
+        hasHit = true;
+        bestTri = first + i;
+        if (!closest) return true;
+      }
+    }
+    cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
   }
   if (hasHit && closest) {
     // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
-    const DTriShade &s = m.shade[bestTri];
+    const uint4 *s = (RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade)) + 3 * (size_t) bestTri;
+    const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
     const float bc = 1.f - ba - bb;
-    h.N = (ld3(s.n0) * ba + ld3(s.n1) * bb) + ld3(s.n2) * bc;
-    h.mtlID = s.mtl;
+    const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)),
+             n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));
+    h.N = (n0 * ba + n1 * bb) + n2 * bc;
+    h.mtlID = (int) s2.y;
     h.node = k;
   }
   return hasHit;
 }
 
 // Scene::TraceNodeNormal (src/scene/scene.cpp:50-74): closest hit over every node in pre-order.
-template <bool STATS>
-__device__ __forceinline__ bool traceClosest(const DScene &sc, const Ray &world, Hit &h, uint32_t *stack,
-                                             DCounters &cnt)
+template <bool RES, bool STATS>
+__device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DScene &sc, const Ray &world, Hit &h,
+                                             uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_normal++;
   const Ray r0 = toNode(sc.inst[0], world);
@@ -303,7 +331,7 @@ __device__ __forceinline__ bool traceClosest(const DScene &sc, const Ray &world,
     bool hit;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, true);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, true);
-    else hit = hitMesh<STATS>(sc.mesh[sc.inst[k].mesh], r, h, k, true, stack, cnt);
+    else hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, true, stack, cnt);
     any |= hit;
   }
   if (any) {
@@ -319,9 +347,9 @@ __device__ __forceinline__ bool traceClosest(const DScene &sc, const Ray &world,
 }
 
 // GenLight::Shadow -> Scene::TraceNodeShadow (src/lights/lights.cpp:39-48, src/scene/scene.cpp:35-46)
-template <bool STATS>
-__device__ __forceinline__ float shadow(const DScene &sc, const Ray &world, float t_max, uint32_t *stack,
-                                        DCounters &cnt)
+template <bool RES, bool STATS>
+__device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &sc, const Ray &world, float t_max,
+                                        uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_shadow++;
   Hit h;
@@ -335,7 +363,7 @@ __device__ __forceinline__ float shadow(const DScene &sc, const Ray &world, floa
     bool hit;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
-    else hit = hitMesh<STATS>(sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt);
+    else hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt);
     if (hit) return 0.0f;
   }
   return 1.0f;
@@ -347,22 +375,23 @@ __device__ __forceinline__ float shadow(const DScene &sc, const Ray &world, floa
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float inverseSquareFalloff(f3 v) { return qmin(1.f, 1.f / dot(v, v)); }
 
-template <bool STATS>
-__device__ __forceinline__ f3 illuminate(const DScene &sc, const qa_light &l, f3 p, uint32_t *stack, DCounters &cnt)
+template <bool RES, bool STATS>
+__device__ __forceinline__ f3 illuminate(const SceneMem<RES> mem, const DScene &sc, const qa_light &l, f3 p,
+                                         uint32_t *stack, DCounters &cnt)
 {
   const f3 intensity = ld3(l.intensity);
   if (l.type == QA_LIGHT_DIRECT) {
     Ray r;
     r.p = p;
     r.d = normalize(-ld3(l.direction));
-    return intensity * shadow<STATS>(sc, r, QA_BIGFLOAT, stack, cnt);
+    return intensity * shadow<RES, STATS>(mem, sc, r, QA_BIGFLOAT, stack, cnt);
   }
   // point / spot
   const f3 dir = ld3(l.position) - p;
   Ray r;
   r.p = p;
   r.d = normalize(dir);
-  f3 I = (intensity * shadow<STATS>(sc, r, length(dir), stack, cnt)) * inverseSquareFalloff(dir);
+  f3 I = (intensity * shadow<RES, STATS>(mem, sc, r, length(dir), stack, cnt)) * inverseSquareFalloff(dir);
   if (l.type == QA_LIGHT_SPOT) {
     // SpotLight::GetAttenuation(Direction(p)) (lights.cpp:128-143)
     const f3 d = normalize(p - ld3(l.position));
@@ -400,20 +429,27 @@ struct Path {
 };
 
 // ---------------------------------------------------------------------------------------------
-// The kernel
+// The kernel.  Dynamic LDS: [resident scene image (RES) | traversal stacks (stackDepth x 256)]
 // ---------------------------------------------------------------------------------------------
-template <bool STATS>
+template <bool RES, bool LIGHTS, bool STATS>
 __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const RenderParams rp)
 {
-  __shared__ uint32_t s_stack[QA_STACK * QA_BLOCK];
-  uint32_t *stack = s_stack + threadIdx.x;
+  extern __shared__ uint4 s_dyn[];
+  SceneMem<RES> mem;
+  mem.img = s_dyn;
+  if (RES) {
+    for (uint32_t i = threadIdx.x; i < sc.residentVec4; i += QA_BLOCK) s_dyn[i] = sc.resident[i];
+    __syncthreads();
+  }
+  uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn + (RES ? sc.residentVec4 : 0)) + threadIdx.x;
+  const uint4 *mtlTable = RES ? s_dyn + sc.resMaterials : reinterpret_cast<const uint4 *>(sc.mtl);
 
   // work items walk 8x8 pixel tiles (a wave starts on a compact screen patch); ragged right /
-  // bottom tiles contain padding slots that are simply skipped
-  const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
+  // bottom tiles contain padding slots that are simply skipped.
   // A launch may own only every tile_row_step-th 8-row strip of the region (round-robin image
   // partition between GPUs, the reference's ThreadRender(tileStart=rank, step=size),
   // src/renderers/renderer.cpp:383-387); its outputs are packed strip after strip.
+  const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
   const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
   const unsigned lane = __lane_id();
@@ -422,13 +458,20 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
 
   // pixel state
   int px = 0, py = 0;
-  unsigned q = 0;           // region-local pixel index
+  unsigned q = 0;           // output index of the pixel
   uint32_t rng = 1;
   int sidx = 0;
   f3 mean = F3(0, 0, 0), cstd = F3(0, 0, 0);
   float depth = 0.f;
   Path path;
   path.primary = true;
+  path.ray.p = F3(0, 0, 0);
+  path.ray.d = F3(0, 0, 1);
+  path.T = F3(0, 0, 0);
+  path.L = F3(0, 0, 0);
+  path.absorb = F3(0, 0, 0);
+  path.bounce = 0;
+  path.fromDiffuse = false;
   f3 texpos = F3(0, 0, 0);
 
   bool alive = true, needPixel = true, needSample = false;
@@ -506,13 +549,13 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
       h.front = true;
       h.p = F3(0, 0, 0);
       h.N = F3(0, 0, 0);
-      const bool found = traceClosest<STATS>(sc, path.ray, h, stack, cnt);
+      const bool found = traceClosest<RES, STATS>(mem, sc, path.ray, h, stack, cnt);
       if (path.primary && sidx == 0) depth = found ? h.z : QA_BIGFLOAT;
 
       if (!found) {
         // background for camera rays (renderer.cpp:337-341), environment otherwise
         // (MtlBlinn_PhotonMap.cpp:249-251); textured versions are rejected at upload
-        const f3 c = path.primary ? ld3(sc.background.color) : ld3(sc.environment.color);
+        const f3 c = path.primary ? ld3(sc.background) : ld3(sc.environment);
         path.L = path.L + path.T * c;
         done = true;
       } else {
@@ -524,38 +567,47 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
           path.T = path.T * att;
         }
         const qa_instance &in = sc.inst[h.node];
-        const qa_material *mp = nullptr;
+        int mi = -1;
         bool white = false;
         if (in.mtlset >= 0) {
           const qa_mtlset ms = sc.mtlset[in.mtlset];
           if (ms.multi) {
-            if (h.mtlID >= 0 && h.mtlID < ms.count) mp = &sc.mtl[ms.first + h.mtlID];
+            if (h.mtlID >= 0 && h.mtlID < ms.count) mi = ms.first + h.mtlID;
             else white = true;  // MultiMtl::Shade returns (1,1,1) (materials.h:70-76)
-          } else mp = &sc.mtl[ms.first];
+          } else mi = ms.first;
         }
-        if (mp == nullptr) {
+        if (mi < 0) {
           if (white) path.L = path.L + path.T;
           done = true;
         } else {
-          const qa_material &m = *mp;
+          const uint4 *mr = mtlTable + 6 * (size_t) mi;
+          const uint4 m0 = mr[0], m1 = mr[1], m2 = mr[2], m5 = mr[5];
+          const f3 sampleDiffuse = F3(asF(m0.x), asF(m0.y), asF(m0.z));
+          const float kill = asF(m0.w);
+          const f3 sampleSpecular = F3(asF(m1.x), asF(m1.y), asF(m1.z));
+          const float glossSpec = asF(m1.w);
+          const f3 emission = F3(asF(m2.x), asF(m2.y), asF(m2.z));
+          const uint32_t mflags = m5.w;
           const f3 V = -path.ray.d;
           const f3 N = h.N;
           const f3 Y = dot(N, V) > 0.f ? N : -N;
           const f3 p = h.p;
-          const f3 tK = ld3(m.refraction.color), rK = ld3(m.reflection.color);
-          const f3 sampleSpecular = ld3(m.specular.color);
-          const f3 sampleDiffuse = ld3(m.diffuse.color);
-          path.L = path.L + path.T * ld3(m.emission.color);
+          path.L = path.L + path.T * emission;
 
           // ComputeFresnel (:65-105); skipped when neither lobe can receive energy: with
           // tK = rK = 0 both products below are exactly 0 for any finite Fresnel term.
           f3 sampleTransmission = F3(0, 0, 0), sampleReflection = F3(0, 0, 0);
           f3 tDir = F3(0, 0, 0), rDir = F3(0, 0, 0);
-          const bool specularLobes = (tK.x != 0.f || tK.y != 0.f || tK.z != 0.f || rK.x != 0.f || rK.y != 0.f || rK.z != 0.f);
-          if (specularLobes) {
+          float glossRefl = 0.f, glossRefr = 0.f;
+          if (mflags & QA_MTL_SPECULAR_LOBES) {
+            const uint4 m3 = mr[3], m4 = mr[4];
+            const f3 rK = F3(asF(m3.x), asF(m3.y), asF(m3.z)), tK = F3(asF(m4.x), asF(m4.y), asF(m4.z));
+            glossRefl = asF(m3.w);
+            glossRefr = asF(m4.w);
+            const float ior = asF(m2.w);
             const f3 Z = cross(V, Y);
             const f3 X = normalize(cross(Y, Z));
-            const float nIOR = h.front ? 1.f / m.ior : m.ior;
+            const float nIOR = h.front ? 1.f / ior : ior;
             const float cosI = dot(N, V);
             const float sinI = qsqrt(1 - cosI * cosI);
             const float sinO = qmax(0.f, qmin(1.f, sinI * nIOR));
@@ -576,7 +628,7 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
           const float coefTransmit = lumaT;
           const float coefReflection = coefTransmit + lumaR;
           const float coefDiffuse = coefReflection + lumaD;
-          const float coefSum = coefDiffuse + m.kill;
+          const float coefSum = coefDiffuse + kill;
           const float sel = rsel * coefSum;
           int select;  // 0 transmit, 1 reflect, 2 diffuse, 3 absorb
           if (sel < coefTransmit && lumaT > 0.00001f) select = 0;
@@ -589,19 +641,19 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
           f3 nextDir = F3(0, 0, 0), bxdf = F3(0, 0, 0);
           bool nextFromDiffuse = false;
           if (path.bounce > 0) {
-            if (select == 1 && lumaR > 0.00001f) {
-              if (m.gloss_refl > 0.f) {
-                do { nextDir = normalize(normalize(rDir) + uniformBall(rng, 2.f * m.gloss_refl)); } while (dot(nextDir, Y) < 0);
+            if (select == 1) {
+              if (glossRefl > 0.f) {
+                do { nextDir = normalize(normalize(rDir) + uniformBall(rng, 2.f * glossRefl)); } while (dot(nextDir, Y) < 0);
               } else nextDir = rDir;
               bxdf = sampleReflection;
               spawn = true;
-            } else if (select == 0 && lumaT > 0.00001f) {
-              if (m.gloss_refr > 0.f) {
-                do { nextDir = normalize(normalize(tDir) + uniformBall(rng, 2.f * m.gloss_refr)); } while (dot(nextDir, Y) > 0);
+            } else if (select == 0) {
+              if (glossRefr > 0.f) {
+                do { nextDir = normalize(normalize(tDir) + uniformBall(rng, 2.f * glossRefr)); } while (dot(nextDir, Y) > 0);
               } else nextDir = tDir;
               bxdf = sampleTransmission;
               spawn = true;
-            } else if (select == 2 && lumaD > 0.00001f && !path.fromDiffuse && h.front) {
+            } else if (select == 2 && !path.fromDiffuse && h.front) {
               // SampleDiffuseBxDF (:199-224) + CosWeightedHemisphere (src/core/sampler.cpp:87-103)
               const float r1 = rng1(rng), r2 = rng1(rng);
               const float cosTheta = qsqrt(r1);
@@ -610,11 +662,11 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
               const f3 smp = F3(sinTheta * qcosf(phi), sinTheta * qsinf(phi), cosTheta);
               nextDir = toLocalFrame(N, smp);
               bxdf = sampleDiffuse;
-              if (sampleSpecular.x != 0.f || sampleSpecular.y != 0.f || sampleSpecular.z != 0.f) {
+              if (mflags & QA_MTL_HAS_SPECULAR) {
                 const f3 Ld = normalize(nextDir);
                 const f3 H = normalize(V + Ld);
                 const float cosNH = qmax(0.f, dot(N, H));
-                bxdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, m.gloss_spec);
+                bxdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, glossSpec);
               }
               nextFromDiffuse = true;
               spawn = true;
@@ -622,17 +674,17 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
           }
 
           // direct lighting (:481-498): every non-ambient light, weight 1/#lights (ambient counted)
-          if (sc.num_lights > 0) {
+          if (LIGHTS) {
             const float normCoefDI = 1.f / (float) sc.num_lights;
             for (int li = 0; li < sc.num_lights; ++li) {
               const qa_light &l = sc.light[li];
               if (l.type == QA_LIGHT_AMBIENT) continue;
-              const f3 intensity = illuminate<STATS>(sc, l, p, stack, cnt) * normCoefDI;
+              const f3 intensity = illuminate<RES, STATS>(mem, sc, l, p, stack, cnt) * normCoefDI;
               const f3 Ld = normalize(-lightDirection(l, p));
               const f3 H = normalize(V + Ld);
               const float cosNL = qmax(0.f, dot(N, Ld));
               const float cosNH = qmax(0.f, dot(N, H));
-              const f3 brdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, m.gloss_spec);
+              const f3 brdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, glossSpec);
               path.L = path.L + path.T * ((intensity * cosNL) * brdf);
             }
           }
@@ -642,7 +694,7 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
             path.ray.p = p;
             path.ray.d = normalize(nextDir);
             path.T = path.T * bxdf;
-            path.absorb = ld3(m.absorption);
+            path.absorb = F3(asF(m5.x), asF(m5.y), asF(m5.z));
             path.bounce -= 1;
             path.fromDiffuse = nextFromDiffuse;
             path.primary = false;

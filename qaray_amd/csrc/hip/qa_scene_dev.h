@@ -4,16 +4,21 @@
 // it the arrays the traversal actually streams:
 //
 //   DNode   32 B   cy::BVH node padded from 28 B so a sibling pair (children are adjacent:
-//                  src/ext/cyBVH.h:92-116) is one aligned 64-byte read
-//   DTri    64 B   per-triangle intersection record IN LEAF (element) ORDER, so a leaf's
+//                  src/ext/cyBVH.h:92-116) is one aligned 64-byte read (4 x 16 B)
+//   DTri    48 B   per-triangle intersection record IN LEAF (element) ORDER, so a leaf's
 //                  triangles are contiguous: precomputed face normal, projection axis and
 //                  1/area - the values TriObj::IntersectTriangle recomputes for every test
 //                  (src/objects/objects.cpp:212-246); precomputing them on the host with the same
-//                  fp32 operations yields the same bits
-//   DTriShade      per-triangle shading inputs (vertex normals, uv, material id), read once per
+//                  fp32 operations yields the same bits.  3 x 16 B.
+//   DTriShade 48 B per-triangle shading inputs (vertex normals, material id), read once per
 //                  accepted hit
 //   halton         (Halton(s,11), Halton(s,13)) per sample index - identical for every pixel
 //                  (src/scene/scene.cpp:99-102)
+//
+// Small scenes (every BASELINE config whose assets exist) are additionally packed into ONE
+// "resident image" that each workgroup copies into LDS at kernel start: nodes, triangle records,
+// shading records and materials of all meshes (layout: ResidentLayout).  The traversal then never
+// leaves the CU.
 #pragma once
 #include <stdint.h>
 
@@ -27,31 +32,47 @@ struct alignas(32) DNode {
   uint32_t pad;
 };
 
-struct alignas(64) DTri {
+struct alignas(16) DTri {
   float N[3];      // normalize(cross(B-A, C-A))
-  float A[3];
-  float au, av, bu, bv, cu, cv;  // vertices projected on the plane that drops `axis`
+  float A[3];      // (au, av) are the two components of A that survive dropping `axis`
+  float bu, bv, cu, cv;  // B and C projected on the plane that drops `axis`
   float s;         // 1 / TriangleArea(axis, A, B, C)
   uint32_t axis;   // 0,1,2: dominant axis of N
-  uint32_t face;   // original face id
+};
+static_assert(sizeof(DTri) == 48, "DTri must be 3 x 16 bytes");
+
+struct alignas(16) DTriShade {
+  float n0[3], n1[3], n2[3];   // vertex normals (TriMesh::GetNormal interpolates them)
+  int32_t mtl;
+  uint32_t face;               // original face id (texture coordinates are looked up by it)
   uint32_t pad;
 };
+static_assert(sizeof(DTriShade) == 48, "DTriShade must be 3 x 16 bytes");
 
-struct DTriShade {
-  float n0[3], n1[3], n2[3];   // vertex normals (TriMesh::GetNormal interpolates them)
-  float t0[2], t1[2], t2[2];   // texture vertices (valid when hasVT)
-  int32_t mtl;
-  int32_t hasVT;
+// Material record in the order the shader reads it (no texture references: plain colours)
+struct alignas(16) DMaterial {
+  float diffuse[3], kill;
+  float specular[3], gloss_spec;
+  float emission[3], ior;
+  float reflection[3], gloss_refl;
+  float refraction[3], gloss_refr;
+  float absorption[3];
+  uint32_t flags;              // bit0: reflection or refraction colour non-zero, bit1: specular non-zero
 };
+static_assert(sizeof(DMaterial) == 96, "DMaterial must be 6 x 16 bytes");
+#define QA_MTL_SPECULAR_LOBES 1u
+#define QA_MTL_HAS_SPECULAR 2u
 
 struct DMesh {
   float bmin[3], bmax[3];
-  const DNode *nodes;          // [num_nodes], root = 1
+  const DNode *nodes;          // [num_nodes], root = 1 (global memory copy)
   const DTri *tris;            // [num_faces] in element order
   const DTriShade *shade;      // [num_faces] in element order
   uint32_t num_faces, num_nodes;
   uint32_t rootData;           // nodes[1].data
-  uint32_t pad;
+  uint32_t stackNeed;          // deepest traversal stack this BVH can require
+  // offsets (in 16-byte units) of this mesh's arrays inside the resident image
+  uint32_t resNodes, resTris, resShade, pad;
 };
 
 struct DCamera {
@@ -64,15 +85,18 @@ struct DScene {
   const unsigned char *blob;
   const qa_instance *inst;
   const qa_mtlset *mtlset;
-  const qa_material *mtl;
+  const DMaterial *mtl;        // [num_materials] (global memory copy)
   const qa_light *light;
-  const qa_texmap *texmap;
-  const qa_texture *tex;
   const DMesh *mesh;
   const float *halton;         // 2 floats per sample index, [halton_count]
+  const uint4 *resident;       // resident image (nodes | tris | shade | materials), or nullptr
   DCamera cam;
-  qa_texcolor background, environment;
-  int32_t num_inst, num_lights, halton_count, pad;
+  float background[3], environment[3];
+  int32_t num_inst, num_lights, halton_count, num_materials;
+  uint32_t residentVec4;       // size of the resident image in 16-byte units (0 = not resident)
+  uint32_t resMaterials;       // offset of the material table inside it (16-byte units)
+  uint32_t stackNeed;          // max over meshes
+  uint32_t pad;
 };
 
 struct DCounters {
