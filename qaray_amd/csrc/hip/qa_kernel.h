@@ -477,18 +477,20 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
   bool alive = true, needPixel = true, needSample = false;
 
   for (;;) {
-    // ---- A. pixel fetch: one atomic per wavefront for all lanes that ran out of work --------
+    // ---- A. tile fetch: a wave owns one 8x8 pixel tile at a time (lane = pixel).  Rays of one
+    // tile are coherent and cost about the same, so background tiles (every ray misses the scene
+    // bounds) never share a wave with expensive ones.  One atomic per wave and tile; lanes that
+    // finish their pixel early wait for the rest of the tile (the spread is a few percent).
+    const unsigned long long aliveMask = __ballot(alive);
     const unsigned long long want = __ballot(alive && needPixel);
-    if (want) {
-      const unsigned n = (unsigned) __popcll(want);
+    if (want && want == aliveMask) {
       unsigned base = 0;
       const int leader = __ffsll((long long) want) - 1;
-      if ((int) lane == leader) base = (*rp.stop_flag) ? total : atomicAdd(rp.work_counter, n);
+      if ((int) lane == leader) base = (*rp.stop_flag) ? total : atomicAdd(rp.work_counter, 64u);
       base = __shfl(base, leader);
-      if (alive && needPixel) {
-        const unsigned rank = (unsigned) __popcll(want & ((1ull << lane) - 1ull));
-        const unsigned w = base + rank;
-        if (base >= total || w >= total) {
+      if (alive) {
+        const unsigned w = base + lane;
+        if (base >= total) {
           alive = false;
         } else {
           const unsigned tile = w / 64, in = w % 64;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const 
             needSample = true;
             needPixel = false;
           }
-          // else: padding slot of a ragged tile - ask again next iteration
+          // else: padding slot of a ragged tile - this lane sits the tile out
         }
       }
     }
