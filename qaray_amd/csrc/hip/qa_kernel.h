@@ -36,6 +36,9 @@
 namespace qa {
 
 #define QA_BLOCK 256
+#ifndef QA_MIN_WAVES
+#define QA_MIN_WAVES 4          /* waves per SIMD the register allocator must leave room for */
+#endif
 #define QA_BIAS 0.005f         /* src/objects/objects.cpp:19 */
 #define QA_DONE 0xFFFFFFFFu    /* traversal sentinel (has the leaf bit set, never a real node word) */
 
@@ -203,43 +206,55 @@ __device__ __forceinline__ void boxEntryExit(const Ray &ray, f3 drcp, f3 bmin, f
   exit_ = qmin(t1.x, qmin(t1.y, t1.z));
 }
 
+// Fast slab test for rays whose direction has no near-zero component (|d| >= 1e-7 on every axis,
+// the reference's threshold): then every product below is finite and not NaN, and the reference's
+// MIN/MAX macros return the same VALUES as the hardware min/max instructions (they can only differ
+// in the sign of a zero, which the comparisons that consume entry/exit cannot see).
+// -(p - b) and (b - p) are the same number up to the sign of zero for the same reason.
+__device__ __forceinline__ void boxEntryExitFast(const Ray &ray, f3 drcp, f3 bmin, f3 bmax, float &entry, float &exit_)
+{
+  const f3 p0 = (bmin - ray.p) * drcp;
+  const f3 p1 = (bmax - ray.p) * drcp;
+  entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z));
+  exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z));
+}
+
 // TriObj::IntersectTriangle (src/objects/objects.cpp:212-306) on a precomputed 48-byte record
 // (three 16-byte words q0..q2, see DTri).  TriangleArea(axis, P, Q, R) =
 // (Q.u-P.u)*(R.v-P.v) - (R.u-P.u)*(Q.v-P.v) with (u,v) the two coordinates kept after dropping
-// `axis` (objects.cpp:30-41).
+// `axis` (objects.cpp:30-41).  Written without early exits: in a 64-wide wave some lane almost
+// always survives each of the reference's five rejections, so the branches only cost; every
+// quantity is a pure function of the inputs, and the accept condition is the conjunction of the
+// reference's tests in its own order (a rejected test's later values are simply ignored).
 __device__ __forceinline__ bool hitTriangle(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, Hit &h,
                                             float &ba, float &bb)
 {
   const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
   const f3 A = F3(asF(q0.w), asF(q1.x), asF(q1.y));
   const float dz = dot(ray.d, N);
-  if (qabs(dz) < 1e-7f) return false;
   const float pz = dot(ray.p - A, N);
-  // t = -pz/dz <= 0 <= bias whenever pz and dz have the same sign or pz is zero: the reference
-  // rejects those after its division (objects.cpp:226-229); decide them without dividing.
-  if ((pz > 0 && dz > 0) || (pz < 0 && dz < 0) || pz == 0) return false;
   const float t = -pz / dz;
-  if (t <= QA_BIAS) return false;
-  if (h.z > t) {
-    const uint32_t axis = q2.w;
-    const f3 p = ray.p + ray.d * t;
-    const float pu = (axis == 0) ? p.y : p.x;
-    const float pv = (axis == 2) ? p.y : p.z;
-    const float au = (axis == 0) ? A.y : A.x;
-    const float av = (axis == 2) ? A.y : A.z;
-    const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
-    const float a = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
-    const float b = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
-    const float c = 1.f - a - b;
-    if (a < 0 || b < 0 || c < 0) return false;
+  bool ok = !(qabs(dz) < 1e-7f) && !(t <= QA_BIAS) && (h.z > t);
+  const uint32_t axis = q2.w;
+  const f3 p = ray.p + ray.d * t;
+  const bool ax0 = (axis == 0), ax2 = (axis == 2);
+  const float pu = ax0 ? p.y : p.x;
+  const float pv = ax2 ? p.y : p.z;
+  const float au = ax0 ? A.y : A.x;
+  const float av = ax2 ? A.y : A.z;
+  const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
+  const float a = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
+  const float b = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
+  const float c = 1.f - a - b;
+  ok = ok && !(a < 0 || b < 0 || c < 0);
+  if (ok) {
     h.z = t;
     h.p = p;
     h.front = (dz <= 0);
     ba = a;
     bb = b;
-    return true;
   }
-  return false;
+  return ok;
 }
 
 // TriObj::IntersectRay + TraceBVHNode (src/objects/objects.cpp:310-420).  The traversal stack
@@ -257,6 +272,8 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
   }
   if (m.num_faces == 0) return false;
+  // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
+  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
   const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
   const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
   bool hasHit = false;
@@ -271,8 +288,15 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
       const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
       const uint4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
       float entry0, exit0, entry1, exit1;
-      boxEntryExit(ray, drcp, F3(asF(a0.x), asF(a0.y), asF(a0.z)), F3(asF(a0.w), asF(a1.x), asF(a1.y)), entry0, exit0);
-      boxEntryExit(ray, drcp, F3(asF(b0.x), asF(b0.y), asF(b0.z)), F3(asF(b0.w), asF(b1.x), asF(b1.y)), entry1, exit1);
+      const f3 min0 = F3(asF(a0.x), asF(a0.y), asF(a0.z)), max0 = F3(asF(a0.w), asF(a1.x), asF(a1.y));
+      const f3 min1 = F3(asF(b0.x), asF(b0.y), asF(b0.z)), max1 = F3(asF(b0.w), asF(b1.x), asF(b1.y));
+      if (fastSlab) {
+        boxEntryExitFast(ray, drcp, min0, max0, entry0, exit0);
+        boxEntryExitFast(ray, drcp, min1, max1, entry1, exit1);
+      } else {
+        boxEntryExit(ray, drcp, min0, max0, entry0, exit0);
+        boxEntryExit(ray, drcp, min1, max1, entry1, exit1);
+      }
       const float t_max = h.z;
       const bool hit0 = (entry0 < t_max && entry0 < exit0);
       const bool hit1 = (entry1 < t_max && entry1 < exit1);
@@ -432,7 +456,7 @@ struct Path {
 // The kernel.  Dynamic LDS: [resident scene image (RES) | traversal stacks (stackDepth x 256)]
 // ---------------------------------------------------------------------------------------------
 template <bool RES, bool LIGHTS, bool STATS>
-__global__ __launch_bounds__(QA_BLOCK) void qa_integrate(const DScene sc, const RenderParams rp)
+__global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
   SceneMem<RES> mem;

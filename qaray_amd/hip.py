@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "lib", "libqaray_hip.so")
+HIP_LIB_PATH = os.environ.get("QA_HIP_LIB") or os.path.join(_HERE, "lib", "libqaray_hip.so")  # QA_HIP_LIB: A/B builds
 
 QA_RENDER_STATS = 1
 DEFAULT_SEED = 0x51A7A7
