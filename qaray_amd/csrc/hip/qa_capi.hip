@@ -327,7 +327,9 @@ static int PrepareScene(qa_ctx *c)
   ds.stackNeed = stackNeedMax;
   c->stackDepth = stackNeedMax < 8 ? 8 : stackNeedMax;
   // LDS budget per workgroup: resident image + stacks; small scenes stay entirely on the CU
-  const size_t stackBytes = (size_t) c->stackDepth * QA_BLOCK * sizeof(uint32_t);
+  ds.stackDepth = c->stackDepth;
+  // traversal stacks + 6 accumulator floats per lane (mean, variance)
+  const size_t stackBytes = ((size_t) c->stackDepth + 6) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = image.size() * sizeof(uint4);
   if (stackBytes > kMaxLdsPerBlock) return Fail(QA_EUNSUPPORTED, "BVH too deep for the LDS traversal stack");
   c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget);
@@ -353,6 +355,10 @@ static int PrepareScene(qa_ctx *c)
   ds.num_inst = (int) h->num_instances;
   ds.num_lights = (int) h->num_lights;
   ds.num_materials = (int) h->num_materials;
+  {
+    static const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
+    ds.rootIdentity = (memcmp(inst[0].tm, I, 36) == 0 && memcmp(inst[0].itm, I, 36) == 0 && memcmp(inst[0].pos, Z, 12) == 0) ? 1 : 0;
+  }
   c->haveScene = true;
   return SelectKernel(c);
 }

@@ -109,6 +109,19 @@ __device__ __forceinline__ Ray toNode(const qa_instance &in, const Ray &r)
   return o;
 }
 
+// The root node of a qaray scene never carries a transform (Node::Init, src/core/node.cpp:41-48):
+// tm = itm = I, pos = 0.  Multiplying by the identity and subtracting zero return their operand
+// (up to the sign of a zero), so Node::ToNodeCoords at the root reduces to dir' = (p + dir) - p,
+// whose two roundings are what the reference performs and must be kept.
+__device__ __forceinline__ Ray rootRay(const DScene &sc, const Ray &world)
+{
+  if (!sc.rootIdentity) return toNode(sc.inst[0], world);
+  Ray o;
+  o.p = world.p;
+  o.d = (world.p + world.d) - world.p;
+  return o;
+}
+
 // Local ray of instance k: the root's transform has already been applied (r0); walk the rest of
 // the ancestor chain top-down.  All lanes work on the same k, so the chain is wave-uniform.
 __device__ __forceinline__ Ray localRay(const DScene &sc, int k, const Ray &r0)
@@ -346,7 +359,7 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
                                              uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_normal++;
-  const Ray r0 = toNode(sc.inst[0], world);
+  const Ray r0 = rootRay(sc, world);
   bool any = false;
   for (int k = 1; k < sc.num_inst; ++k) {
     const int type = sc.inst[k].obj_type;
@@ -362,6 +375,10 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
     // Node::FromNodeCoords at every level from the hit node up to and including the root
     // (src/core/node.cpp:127-139); the reference applies them as its recursion unwinds.
     for (int a = h.node; a >= 0; a = sc.inst[a].parent) {
+      if (a == 0 && sc.rootIdentity) {
+        h.N = normalize(h.N);  // identity root: p unchanged, the normal is still re-normalised
+        break;
+      }
       const qa_instance &in = sc.inst[a];
       h.p = mulMV(in.tm, h.p) + ld3(in.pos);
       h.N = normalize(mulTMV(in.itm, h.N));
@@ -379,7 +396,7 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
   Hit h;
   h.z = t_max;
   h.node = -1;
-  const Ray r0 = toNode(sc.inst[0], world);
+  const Ray r0 = rootRay(sc, world);
   for (int k = 1; k < sc.num_inst; ++k) {
     const int type = sc.inst[k].obj_type;
     if (type == QA_OBJ_NONE) continue;
@@ -445,8 +462,8 @@ struct Path {
   Ray ray;          // next ray to trace (world space)
   f3 T;             // throughput
   f3 L;             // radiance gathered by this sample so far
-  f3 absorb;        // absorption of the medium the current ray was spawned from (Beer's law on a
-                    // back-face exit, ComputeSecondaryRay :244-248)
+  int absorbMtl;    // material the current ray was spawned from: its absorption applies on a
+                    // back-face exit (Beer's law, ComputeSecondaryRay :244-248); -1 for camera rays
   int bounce;       // bounceCount the next hit is shaded with
   bool fromDiffuse; // hInfo.c.hasDiffuseHit of the next hit
   bool primary;     // camera ray
@@ -466,6 +483,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
     __syncthreads();
   }
   uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn + (RES ? sc.residentVec4 : 0)) + threadIdx.x;
+  // per-lane sample accumulators (running mean + variance of SuperSamplerHalton) live in LDS: they
+  // are touched once per sample, registers are better spent on the traversal
+  float *acc = reinterpret_cast<float *>(stack + (size_t) sc.stackDepth * QA_BLOCK - threadIdx.x) + threadIdx.x;
   const uint4 *mtlTable = RES ? s_dyn + sc.resMaterials : reinterpret_cast<const uint4 *>(sc.mtl);
 
   // work items walk 8x8 pixel tiles (a wave starts on a compact screen patch); ragged right /
@@ -485,15 +505,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
   unsigned q = 0;           // output index of the pixel
   uint32_t rng = 1;
   int sidx = 0;
-  f3 mean = F3(0, 0, 0), cstd = F3(0, 0, 0);
-  float depth = 0.f;
   Path path;
   path.primary = true;
   path.ray.p = F3(0, 0, 0);
   path.ray.d = F3(0, 0, 1);
   path.T = F3(0, 0, 0);
   path.L = F3(0, 0, 0);
-  path.absorb = F3(0, 0, 0);
+  path.absorbMtl = -1;
   path.bounce = 0;
   path.fromDiffuse = false;
   f3 texpos = F3(0, 0, 0);
@@ -527,9 +545,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
             q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
             rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
             sidx = 0;
-            mean = F3(0, 0, 0);
-            cstd = F3(0, 0, 0);
-            depth = 0.f;
+            for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;
             needSample = true;
             needPixel = false;
           }
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
       path.ray.d = normalize(cpt - campos);
       path.T = F3(1, 1, 1);
       path.L = F3(0, 0, 0);
-      path.absorb = F3(0, 0, 0);
+      path.absorbMtl = -1;
       path.bounce = rp.max_bounce;
       path.fromDiffuse = false;
       path.primary = true;
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
       h.p = F3(0, 0, 0);
       h.N = F3(0, 0, 0);
       const bool found = traceClosest<RES, STATS>(mem, sc, path.ray, h, stack, cnt);
-      if (path.primary && sidx == 0) depth = found ? h.z : QA_BIGFLOAT;
+      if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
 
       if (!found) {
         // background for camera rays (renderer.cpp:337-341), environment otherwise
@@ -588,8 +604,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
         // ---- D. shade: MtlBlinn_PhotonMap::Shade (MtlBlinn_PhotonMap.cpp:256-500) -----------
         // Beer-Lambert attenuation of everything this hit returns, when the ray arrives from
         // inside (ComputeSecondaryRay :244-248)
-        if (!path.primary && !h.front) {
-          const f3 att = F3(qexpf(-path.absorb.x * h.z), qexpf(-path.absorb.y * h.z), qexpf(-path.absorb.z * h.z));
+        if (!path.primary && !h.front && path.absorbMtl >= 0) {
+          const uint4 ab = mtlTable[6 * (size_t) path.absorbMtl + 5];
+          const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
           path.T = path.T * att;
         }
         const qa_instance &in = sc.inst[h.node];
@@ -720,7 +737,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
             path.ray.p = p;
             path.ray.d = normalize(nextDir);
             path.T = path.T * bxdf;
-            path.absorb = F3(asF(m5.x), asF(m5.y), asF(m5.z));
+            path.absorbMtl = mi;
             path.bounce -= 1;
             path.fromDiffuse = nextFromDiffuse;
             path.primary = false;
@@ -734,9 +751,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
     // ---- E. sample finished: SuperSamplerHalton::Accumulate / Loop (scene.cpp:92-121) ---------
     if (alive && done) {
       const float inv = (float) (sidx + 1);
+      f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
+      f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
       const f3 dc = (path.L - mean) / inv;
       mean = mean + dc;
       if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
+      acc[0] = mean.x; acc[QA_BLOCK] = mean.y; acc[2 * QA_BLOCK] = mean.z;
+      acc[3 * QA_BLOCK] = cstd.x; acc[4 * QA_BLOCK] = cstd.y; acc[5 * QA_BLOCK] = cstd.z;
       ++sidx;
       const bool more = sidx < rp.spp_min ||
                         (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
@@ -746,7 +767,6 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
         rp.rgb[3 * q + 0] = mean.x;
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
-        rp.depth[q] = depth;
         rp.ns[q] = (uint32_t) sidx;
         cnt.pixels++;
         needPixel = true;

@@ -96,7 +96,9 @@ struct DScene {
   uint32_t residentVec4;       // size of the resident image in 16-byte units (0 = not resident)
   uint32_t resMaterials;       // offset of the material table inside it (16-byte units)
   uint32_t stackNeed;          // max over meshes
-  uint32_t pad;
+  uint32_t rootIdentity;       // instance 0 has tm = itm = I and pos = 0 (always, for XML scenes)
+  uint32_t stackDepth;         // entries per lane of the LDS traversal stack
+  uint32_t pad[3];
 };
 
 struct DCounters {
