@@ -54,7 +54,7 @@ struct qa_ctx {
   int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
   void (*kernel)(const DScene, const RenderParams) = nullptr;
   void (*kernelStats)(const DScene, const RenderParams) = nullptr;
-  bool resident = false;
+  bool resident = false, textured = false, area = false;
   uint32_t stackDepth = 32;
   size_t ldsBytes = 0;
 };
@@ -112,14 +112,20 @@ typedef void (*KernelFn)(const DScene, const RenderParams);
 static const size_t kMaxLdsPerBlock = 64 * 1024;      // dynamic LDS a workgroup may ask for without opt-in
 static const size_t kResidentLdsBudget = 40 * 1024;   // image + stacks: keeps 4 workgroups per CU (160 KB LDS)
 
-static KernelFn PickKernel(bool resident, bool lights, bool stats)
+// variants: scene memory (LDS-resident | global) x shading (no lights | lights | + textures | + area
+// lights | + both) x stats
+template <bool RES, bool STATS>
+static KernelFn PickShading(bool lights, bool tex, bool area)
 {
-  if (resident) {
-    if (lights) return stats ? (KernelFn) qa_integrate<true, true, true> : (KernelFn) qa_integrate<true, true, false>;
-    return stats ? (KernelFn) qa_integrate<true, false, true> : (KernelFn) qa_integrate<true, false, false>;
-  }
-  if (lights) return stats ? (KernelFn) qa_integrate<false, true, true> : (KernelFn) qa_integrate<false, true, false>;
-  return stats ? (KernelFn) qa_integrate<false, false, true> : (KernelFn) qa_integrate<false, false, false>;
+  if (area) return tex ? (KernelFn) qa_integrate<RES, true, true, true, STATS> : (KernelFn) qa_integrate<RES, true, false, true, STATS>;
+  if (tex) return (KernelFn) qa_integrate<RES, true, true, false, STATS>;
+  if (lights) return (KernelFn) qa_integrate<RES, true, false, false, STATS>;
+  return (KernelFn) qa_integrate<RES, false, false, false, STATS>;
+}
+static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool stats)
+{
+  if (resident) return stats ? PickShading<true, true>(lights, tex, area) : PickShading<true, false>(lights, tex, area);
+  return stats ? PickShading<false, true>(lights, tex, area) : PickShading<false, false>(lights, tex, area);
 }
 
 // Choose the kernel variant for the uploaded scene and size the persistent grid to what is
@@ -127,8 +133,8 @@ static KernelFn PickKernel(bool resident, bool lights, bool stats)
 static int SelectKernel(qa_ctx *c)
 {
   const bool lights = c->ds.num_lights > 0;
-  c->kernel = PickKernel(c->resident, lights, false);
-  c->kernelStats = PickKernel(c->resident, lights, true);
+  c->kernel = PickKernel(c->resident, lights, c->textured, c->area, false);
+  c->kernelStats = PickKernel(c->resident, lights, c->textured, c->area, true);
   int resident = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
@@ -170,11 +176,19 @@ static int PrepareScene(qa_ctx *c)
   for (uint32_t i = 0; i < h->num_mtlsets; ++i)
     if (mtlset[i].first < 0 || mtlset[i].count < 0 || (uint32_t) (mtlset[i].first + mtlset[i].count) > h->num_materials)
       return Fail(QA_EINVAL, "bad material range");
+  bool area = false;
   for (uint32_t i = 0; i < h->num_lights; ++i)
-    if ((light[i].type == QA_LIGHT_POINT || light[i].type == QA_LIGHT_SPOT) && light[i].size > 0.01f)
-      return Fail(QA_EUNSUPPORTED, "area lights (size > 0.01) need post-order RNG replay: not implemented on the HIP path yet");
-  if (h->num_texmaps > 0 || h->background.texmap >= 0 || h->environment.texmap >= 0)
-    return Fail(QA_EUNSUPPORTED, "textured colours are not implemented on the HIP path yet");
+    if ((light[i].type == QA_LIGHT_POINT || light[i].type == QA_LIGHT_SPOT) && light[i].size > 0.01f) area = true;
+  const qa_texmap *texmaps = QA_BLOB_PTR(qa_texmap, blob, h->off_texmaps);
+  const qa_texture *textures = QA_BLOB_PTR(qa_texture, blob, h->off_textures);
+  for (uint32_t i = 0; i < h->num_texmaps; ++i)
+    if (texmaps[i].texture >= (int) h->num_textures) return Fail(QA_EINVAL, "bad texture index");
+  for (uint32_t i = 0; i < h->num_textures; ++i)
+    if (textures[i].type == QA_TEX_FILE &&
+        (textures[i].width < 0 || textures[i].height < 0 ||
+         !inside(textures[i].off_texels, (uint64_t) textures[i].width * (uint64_t) textures[i].height * 3)))
+      return Fail(QA_EINVAL, "texel array outside the blob");
+  const bool textured = h->num_texmaps > 0;
 
   // ---- derived per-mesh arrays --------------------------------------------------------------
   std::vector<DMesh> dmeshes(h->num_meshes);
@@ -265,8 +279,33 @@ static int PrepareScene(qa_ctx *c)
       s.face = fid;
       s.pad = 0;
     }
+    // texture vertices per triangle (element order); a mesh must have them on every face or none
+    const float *VT = QA_BLOB_PTR(float, blob, m.off_texcoords);
+    std::vector<float> vts;
+    uint32_t withVT = 0;
+    for (uint32_t e = 0; e < m.num_faces; ++e) {
+      const qa_face &f = faces[elements[e]];
+      if (f.vt[0] >= 0 && f.vt[1] >= 0 && f.vt[2] >= 0) {
+        for (int k = 0; k < 3; ++k) if ((uint32_t) f.vt[k] >= m.num_texcoords) return Fail(QA_EINVAL, "texcoord index out of range");
+        ++withVT;
+      }
+    }
+    if (withVT != 0 && withVT != m.num_faces)
+      return Fail(QA_EUNSUPPORTED, "mesh with texture vertices on only some faces");
+    if (withVT && textured) {
+      vts.resize(6 * (size_t) m.num_faces);
+      for (uint32_t e = 0; e < m.num_faces; ++e) {
+        const qa_face &f = faces[elements[e]];
+        for (int k = 0; k < 3; ++k) { vts[6 * e + 2 * k] = VT[2 * f.vt[k]]; vts[6 * e + 2 * k + 1] = VT[2 * f.vt[k] + 1]; }
+      }
+    }
     DMesh &dm = dmeshes[mi];
     memset(&dm, 0, sizeof(dm));
+    dm.hasVT = (withVT && textured) ? 1 : 0;
+    {
+      int rcv;
+      if ((rcv = DeviceCopy(c, vts, &dm.vt)) != QA_OK) return rcv;
+    }
     memcpy(dm.bmin, m.bmin, 12);
     memcpy(dm.bmax, m.bmax, 12);
     dm.num_faces = m.num_faces;
@@ -324,6 +363,44 @@ static int PrepareScene(qa_ctx *c)
   int rc;
   if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
   if ((rc = DeviceCopy(c, dmat, &ds.mtl)) != QA_OK) return rc;
+  // ---- texture-side tables (TEX kernel variants) -------------------------------------------------
+  ds.texmap = QA_BLOB_PTR(qa_texmap, c->dBlob, h->off_texmaps);
+  ds.tex = QA_BLOB_PTR(qa_texture, c->dBlob, h->off_textures);
+  ds.bgTexmap = h->background.texmap;
+  ds.envTexmap = h->environment.texmap;
+  c->textured = textured;
+  c->area = area;
+  if (area) {
+    // hit log of the AREA variants: QA_MAX_PATH x 19 floats per thread of the largest grid
+    const size_t threads = (size_t) c->numCUs * 8 * QA_BLOCK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, threads * QA_MAX_PATH * QA_REC_FLOATS * sizeof(float)));
+    c->sceneAllocs.push_back(p);
+    ds.areaScratch = static_cast<float *>(p);
+  }
+  if (textured) {
+    std::vector<int32_t> mtex(8 * (size_t) h->num_materials, -1);
+    for (uint32_t i = 0; i < h->num_materials; ++i) {
+      mtex[8 * i + 0] = mats[i].diffuse.texmap;
+      mtex[8 * i + 1] = mats[i].specular.texmap;
+      mtex[8 * i + 2] = mats[i].emission.texmap;
+      mtex[8 * i + 3] = mats[i].reflection.texmap;
+      mtex[8 * i + 4] = mats[i].refraction.texmap;
+      for (int k = 0; k < 5; ++k) if (mtex[8 * i + k] >= (int) h->num_texmaps) return Fail(QA_EINVAL, "bad texmap index");
+    }
+    if ((rc = DeviceCopy(c, mtex, &ds.mtlTex)) != QA_OK) return rc;
+    // Texture::Sample's elliptical taps (src/core/texture.cpp:39-46), i = 1..31, host libm
+    std::vector<float> taps(62);
+    for (int i = 1; i < 32; ++i) {
+      float x = HaltonF(i, 2), y = HaltonF(i, 3);
+      const float r = sqrtf(x) * 0.5f;
+      x = r * sinf(y * (float) M_PI * 2);
+      y = r * cosf(y * (float) M_PI * 2);
+      taps[2 * (i - 1)] = x;
+      taps[2 * (i - 1) + 1] = y;
+    }
+    if ((rc = DeviceCopy(c, taps, &ds.texFilter)) != QA_OK) return rc;
+  }
   ds.stackNeed = stackNeedMax;
   c->stackDepth = stackNeedMax < 8 ? 8 : stackNeedMax;
   // LDS budget per workgroup: resident image + stacks; small scenes stay entirely on the CU
@@ -377,6 +454,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (x0 < 0 || y0 < 0 || x1 > c->ds.cam.width || y1 > c->ds.cam.height || x1 <= x0 || y1 <= y0)
     return Fail(QA_EINVAL, "region outside the image");
   if (spp_min < 0 || spp_max < spp_min || spp_max < 1 || max_bounce < 0) return Fail(QA_EINVAL, "bad spp / bounce");
+  if (c->area && max_bounce + 1 > QA_MAX_PATH) return Fail(QA_EUNSUPPORTED, "area lights: maxBounce must be <= 7");
   if (!d_rgb || !d_depth || !d_ns) return Fail(QA_EINVAL, "null output buffer");
   int rc = EnsureHalton(c, spp_max);
   if (rc != QA_OK) return rc;

@@ -32,6 +32,7 @@
 #include "qa_device_math.h"
 #include "qa_scene_dev.h"
 #include "qa_seed.h"
+#include "qa_texture_dev.h"
 
 namespace qa {
 
@@ -40,9 +41,11 @@ namespace qa {
 #define QA_MIN_WAVES 4          /* waves per SIMD the register allocator must leave room for */
 #endif
 #define QA_BIAS 0.005f         /* src/objects/objects.cpp:19 */
+#define QA_DX 0.01f            /* DiffRay::dx = dy, src/core/ray.cpp:31-32 */
 #define QA_DONE 0xFFFFFFFFu    /* traversal sentinel (has the leaf bit set, never a real node word) */
 
 struct Ray { f3 p, d; };
+struct RayDiff { f3 dx, dy; };  // directions of the x / y differential rays (they share the origin)
 
 struct Hit {
   float z;      // world-parametric distance (rays are not renormalised in node space)
@@ -107,6 +110,42 @@ __device__ __forceinline__ Ray toNode(const qa_instance &in, const Ray &r)
   o.p = mulMV(in.itm, r.p - pos);
   o.d = mulMV(in.itm, (r.p + r.d) - pos) - o.p;
   return o;
+}
+
+// Node::ToNodeCoords(DiffRay) (src/core/node.cpp:119-126) for the x / y rays: same origin as the
+// central ray, so only the direction needs its own transform.  `before` is the central ray before
+// this level, `afterP` its origin after it.
+__device__ __forceinline__ f3 toNodeDir(const qa_instance &in, f3 beforeP, f3 afterP, f3 dir)
+{
+  return mulMV(in.itm, (beforeP + dir) - ld3(in.pos)) - afterP;
+}
+__device__ __forceinline__ void localRayDiff(const DScene &sc, int k, const Ray &world, const RayDiff &wd, Ray &r, RayDiff &rd)
+{
+  // root level
+  Ray cur;
+  RayDiff cd;
+  if (sc.rootIdentity) {
+    cur.p = world.p;
+    cur.d = (world.p + world.d) - world.p;
+    cd.dx = (world.p + wd.dx) - world.p;
+    cd.dy = (world.p + wd.dy) - world.p;
+  } else {
+    cur = toNode(sc.inst[0], world);
+    cd.dx = toNodeDir(sc.inst[0], world.p, cur.p, wd.dx);
+    cd.dy = toNodeDir(sc.inst[0], world.p, cur.p, wd.dy);
+  }
+  int chain[QA_MAX_NODE_DEPTH];
+  int n = 0;
+  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = sc.inst[a].parent) chain[n++] = a;
+  for (int q = n - 1; q >= 0; --q) {
+    const qa_instance &in = sc.inst[chain[q]];
+    const Ray nx = toNode(in, cur);
+    cd.dx = toNodeDir(in, cur.p, nx.p, cd.dx);
+    cd.dy = toNodeDir(in, cur.p, nx.p, cd.dy);
+    cur = nx;
+  }
+  r = cur;
+  rd = cd;
 }
 
 // The root node of a qaray scene never carries a transform (Node::Init, src/core/node.cpp:41-48):
@@ -274,9 +313,12 @@ __device__ __forceinline__ bool hitTriangle(const uint4 q0, const uint4 q1, cons
 // holds node DATA words (leaf flag + range, or child index) instead of ids: the word arrives with
 // the node's box when the parent tests its two children, so an inner visit is a single 64-byte
 // read of the sibling pair.
+struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element order) and its barycentrics
+
 template <bool RES, bool STATS>
 __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
-                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt)
+                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt,
+                                        TriPick &pick)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
   {
@@ -349,14 +391,19 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     h.N = (n0 * ba + n1 * bb) + n2 * bc;
     h.mtlID = (int) s2.y;
     h.node = k;
+    pick.tri = bestTri;
+    pick.a = ba;
+    pick.b = bb;
   }
   return hasHit;
 }
 
 // Scene::TraceNodeNormal (src/scene/scene.cpp:50-74): closest hit over every node in pre-order.
-template <bool RES, bool STATS>
-__device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DScene &sc, const Ray &world, Hit &h,
-                                             uint32_t *stack, DCounters &cnt)
+// TEX: also maintains HitInfo::uvw / duvw / hasTexture exactly as the intersectors do (fields are
+// only overwritten by the object types that set them, so stale values survive like in the reference).
+template <bool RES, bool TEX, bool STATS>
+__device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DScene &sc, const Ray &world, const RayDiff &wd,
+                                             Hit &h, TexHit &th, uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_normal++;
   const Ray r0 = rootRay(sc, world);
@@ -364,11 +411,27 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
   for (int k = 1; k < sc.num_inst; ++k) {
     const int type = sc.inst[k].obj_type;
     if (type == QA_OBJ_NONE) continue;
-    const Ray r = localRay(sc, k, r0);
+    Ray r;
+    RayDiff rd;
+    if (TEX) localRayDiff(sc, k, world, wd, r, rd);
+    else r = localRay(sc, k, r0);
     bool hit;
-    if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, true);
-    else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, true);
-    else hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, true, stack, cnt);
+    if (type == QA_OBJ_SPHERE) {
+      hit = hitSphere(r, h, k, true);
+      if (TEX && hit) texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+    } else if (type == QA_OBJ_PLANE) {
+      hit = hitPlane(r, h, k, true);
+      if (TEX && hit) texPlane(r.p, rd.dx, rd.dy, h.p, th);
+    } else {
+      const DMesh &m = sc.mesh[sc.inst[k].mesh];
+      TriPick pick;
+      hit = hitMesh<RES, STATS>(mem, m, r, h, k, true, stack, cnt, pick);
+      if (TEX && hit && m.hasVT) {
+        const uint4 *t = (RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris)) + 3 * (size_t) pick.tri;
+        const float *vt = m.vt + 6 * (size_t) pick.tri;
+        texTriangle(t[0], t[1], t[2], vt, r.p, rd.dx, rd.dy, pick.a, pick.b, th);
+      }
+    }
     any |= hit;
   }
   if (any) {
@@ -404,7 +467,10 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
     bool hit;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
-    else hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt);
+    else {
+      TriPick pick;
+      hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt, pick);
+    }
     if (hit) return 0.0f;
   }
   return 1.0f;
@@ -416,11 +482,40 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float inverseSquareFalloff(f3 v) { return qmin(1.f, 1.f / dot(v, v)); }
 
+// SpotLight::GetAttenuation(Direction(p)) (src/lights/lights.cpp:128-143)
+__device__ __forceinline__ float spotAttenuation(const qa_light &l, f3 p)
+{
+  const f3 d = normalize(p - ld3(l.position));
+  const float cosTheta = dot(d, ld3(l.direction));
+  if (cosTheta < 0) return 0;
+  const float rr = qsqrt(1.f - cosTheta * cosTheta) / cosTheta;
+  if (rr > l.outer) return 0;
+  return rr < l.inner ? 1.f : qpowf((l.outer - rr) / (l.outer - l.inner), 2.f);
+}
+
 template <bool RES, bool STATS>
 __device__ __forceinline__ f3 illuminate(const SceneMem<RES> mem, const DScene &sc, const qa_light &l, f3 p,
-                                         uint32_t *stack, DCounters &cnt)
+                                         uint32_t *stack, DCounters &cnt, uint32_t &rng)
 {
   const f3 intensity = ld3(l.intensity);
+  if (l.type != QA_LIGHT_DIRECT && l.size > 0.01f) {
+    // area light: 16 shadow rays towards points of a ball around the light, 64 as soon as the
+    // running estimate is a penumbra value (src/lights/lights.cpp:52-65,88-100; shadow_spp 16/64 :16-17)
+    int spp = 16, n = 0;
+    float inshadow = 0.0f;
+    while (n < spp) {
+      const f3 dir = (ld3(l.position) + uniformBall(rng, l.size)) - p;
+      Ray r;
+      r.p = p;
+      r.d = normalize(dir);
+      inshadow += (shadow<RES, STATS>(mem, sc, r, length(dir), stack, cnt) - inshadow) * inverseSquareFalloff(dir) / (float) (n + 1);
+      n++;
+      if (inshadow > 0.f && inshadow < 1.f) spp = 64;
+    }
+    f3 I = intensity * inshadow;
+    if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, p);
+    return I;
+  }
   if (l.type == QA_LIGHT_DIRECT) {
     Ray r;
     r.p = p;
@@ -433,19 +528,7 @@ __device__ __forceinline__ f3 illuminate(const SceneMem<RES> mem, const DScene &
   r.p = p;
   r.d = normalize(dir);
   f3 I = (intensity * shadow<RES, STATS>(mem, sc, r, length(dir), stack, cnt)) * inverseSquareFalloff(dir);
-  if (l.type == QA_LIGHT_SPOT) {
-    // SpotLight::GetAttenuation(Direction(p)) (lights.cpp:128-143)
-    const f3 d = normalize(p - ld3(l.position));
-    const float cosTheta = dot(d, ld3(l.direction));
-    float att;
-    if (cosTheta < 0) att = 0;
-    else {
-      const float rr = qsqrt(1.f - cosTheta * cosTheta) / cosTheta;
-      if (rr > l.outer) att = 0;
-      else att = rr < l.inner ? 1.f : qpowf((l.outer - rr) / (l.outer - l.inner), 2.f);
-    }
-    I = I * att;
-  }
+  if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, p);
   return I;
 }
 
@@ -453,6 +536,28 @@ __device__ __forceinline__ f3 lightDirection(const qa_light &l, f3 p)
 {
   if (l.type == QA_LIGHT_DIRECT) return ld3(l.direction);
   return normalize(p - ld3(l.position));
+}
+
+// Direct lighting of one shading point (MtlBlinn_PhotonMap.cpp:481-498): every non-ambient light,
+// weight 1/#lights (ambient counted), Blinn lobe around the half vector.
+template <bool RES, bool STATS>
+__device__ __forceinline__ f3 directLight(const SceneMem<RES> mem, const DScene &sc, f3 p, f3 N, f3 V, f3 kd, f3 ks,
+                                          float gloss, uint32_t *stack, DCounters &cnt, uint32_t &rng)
+{
+  f3 sum = F3(0, 0, 0);
+  const float normCoefDI = 1.f / (float) sc.num_lights;
+  for (int li = 0; li < sc.num_lights; ++li) {
+    const qa_light &l = sc.light[li];
+    if (l.type == QA_LIGHT_AMBIENT) continue;
+    const f3 intensity = illuminate<RES, STATS>(mem, sc, l, p, stack, cnt, rng) * normCoefDI;
+    const f3 Ld = normalize(-lightDirection(l, p));
+    const f3 H = normalize(V + Ld);
+    const float cosNL = qmax(0.f, dot(N, Ld));
+    const float cosNH = qmax(0.f, dot(N, H));
+    const f3 brdf = kd + ks * qpowf(cosNH, gloss);
+    sum = sum + (intensity * cosNL) * brdf;
+  }
+  return sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +577,14 @@ struct Path {
 // ---------------------------------------------------------------------------------------------
 // The kernel.  Dynamic LDS: [resident scene image (RES) | traversal stacks (stackDepth x 256)]
 // ---------------------------------------------------------------------------------------------
-template <bool RES, bool LIGHTS, bool STATS>
+// Area lights draw random numbers, and the reference evaluates a hit's lights only AFTER the whole
+// recursive subtree below it (MtlBlinn_PhotonMap.cpp:374-479 precede :484-498).  AREA variants
+// therefore log one record per hit (19 floats, SoA in a global scratch slab) and replay the lights
+// deepest hit first when the path ends, continuing the same xorshift32 stream.
+#define QA_MAX_PATH 8           /* hits per path an AREA variant can log (maxBounce <= 7) */
+#define QA_REC_FLOATS 19
+
+template <bool RES, bool LIGHTS, bool TEX, bool AREA, bool STATS>
 __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -499,6 +611,16 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
   const unsigned lane = __lane_id();
 
   DCounters cnt = {0, 0, 0, 0, 0, 0};
+  TexTables tt;
+  tt.blob = sc.blob;
+  tt.texmap = sc.texmap;
+  tt.tex = sc.tex;
+  tt.filter = sc.texFilter;
+  int nrec = 0;               // AREA: hits logged for the current path
+  float *rec = sc.areaScratch + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;  // + (lvl*19+f) * recStride
+  const size_t recStride = (size_t) gridDim.x * QA_BLOCK;
+  RayDiff pathDiff;           // TEX: differential directions of the current ray
+  pathDiff.dx = pathDiff.dy = F3(0, 0, 1);
 
   // pixel state
   int px = 0, py = 0;
@@ -571,6 +693,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
       }
       path.ray.p = campos;
       path.ray.d = normalize(cpt - campos);
+      if (TEX) {
+        // DiffRay x / y: the same pixel sample shifted by DiffRay::dx / dy (renderer.cpp:314-317)
+        const f3 xpt = (A + U * (texpos.x + QA_DX)) + V * texpos.y;
+        const f3 ypt = (A + U * texpos.x) + V * (texpos.y + QA_DX);
+        pathDiff.dx = normalize(xpt - campos);
+        pathDiff.dy = normalize(ypt - campos);
+      }
       path.T = F3(1, 1, 1);
       path.L = F3(0, 0, 0);
       path.absorbMtl = -1;
@@ -578,6 +707,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
       path.fromDiffuse = false;
       path.primary = true;
       needSample = false;
+      nrec = 0;
       cnt.samples++;
     }
 
@@ -591,13 +721,23 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
       h.front = true;
       h.p = F3(0, 0, 0);
       h.N = F3(0, 0, 0);
-      const bool found = traceClosest<RES, STATS>(mem, sc, path.ray, h, stack, cnt);
+      TexHit th;
+      th.uvw = F3(0.5f, 0.5f, 0.5f);   // HitInfo::Init (src/core/hitinfo.cpp:31-42)
+      th.duvw0 = th.duvw1 = F3(0, 0, 0);
+      th.hasTexture = false;
+      const bool found = traceClosest<RES, TEX, STATS>(mem, sc, path.ray, pathDiff, h, th, stack, cnt);
       if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
 
       if (!found) {
         // background for camera rays (renderer.cpp:337-341), environment otherwise
         // (MtlBlinn_PhotonMap.cpp:249-251); textured versions are rejected at upload
-        const f3 c = path.primary ? ld3(sc.background) : ld3(sc.environment);
+        f3 c = path.primary ? ld3(sc.background) : ld3(sc.environment);
+        if (TEX) {
+          if (path.primary)
+            c = texColorSample(tt, c, sc.bgTexmap, F3(texpos.x / (float) sc.cam.width, texpos.y / (float) sc.cam.height, 0.f));
+          else
+            c = sampleEnvironment(tt, c, sc.envTexmap, path.ray.d);
+        }
         path.L = path.L + path.T * c;
         done = true;
       } else {
@@ -625,11 +765,19 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
         } else {
           const uint4 *mr = mtlTable + 6 * (size_t) mi;
           const uint4 m0 = mr[0], m1 = mr[1], m2 = mr[2], m5 = mr[5];
-          const f3 sampleDiffuse = F3(asF(m0.x), asF(m0.y), asF(m0.z));
+          f3 sampleDiffuse = F3(asF(m0.x), asF(m0.y), asF(m0.z));
           const float kill = asF(m0.w);
-          const f3 sampleSpecular = F3(asF(m1.x), asF(m1.y), asF(m1.z));
+          f3 sampleSpecular = F3(asF(m1.x), asF(m1.y), asF(m1.z));
           const float glossSpec = asF(m1.w);
-          const f3 emission = F3(asF(m2.x), asF(m2.y), asF(m2.z));
+          f3 emission = F3(asF(m2.x), asF(m2.y), asF(m2.z));
+          int4 mtex0 = make_int4(-1, -1, -1, -1);  // texmaps: diffuse, specular, emission, reflection
+          int mtex4 = -1;                          //          refraction
+          if (TEX) {
+            const int *mt = sc.mtlTex + 8 * (size_t) mi;
+            mtex0 = make_int4(mt[0], mt[1], mt[2], mt[3]);
+            mtex4 = mt[4];
+            emission = mtlSample(tt, th, emission, mtex0.z);
+          }
           const uint32_t mflags = m5.w;
           const f3 V = -path.ray.d;
           const f3 N = h.N;
@@ -644,7 +792,11 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
           float glossRefl = 0.f, glossRefr = 0.f;
           if (mflags & QA_MTL_SPECULAR_LOBES) {
             const uint4 m3 = mr[3], m4 = mr[4];
-            const f3 rK = F3(asF(m3.x), asF(m3.y), asF(m3.z)), tK = F3(asF(m4.x), asF(m4.y), asF(m4.z));
+            f3 rK = F3(asF(m3.x), asF(m3.y), asF(m3.z)), tK = F3(asF(m4.x), asF(m4.y), asF(m4.z));
+            if (TEX) {
+              tK = mtlSample(tt, th, tK, mtex4);
+              rK = mtlSample(tt, th, rK, mtex0.w);
+            }
             glossRefl = asF(m3.w);
             glossRefr = asF(m4.w);
             const float ior = asF(m2.w);
@@ -665,6 +817,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
             sampleReflection = totReflection ? (rK + tK) : (rK + tK * rC);
           }
 
+          if (TEX) {
+            sampleSpecular = mtlSample(tt, th, sampleSpecular, mtex0.y);
+            sampleDiffuse = mtlSample(tt, th, sampleDiffuse, mtex0.x);
+          }
           // RandomSelectMtl (:107-150): one draw, luma-weighted lobes + Russian roulette
           const float lumaT = luma(sampleTransmission), lumaR = luma(sampleReflection), lumaD = luma(sampleDiffuse);
           const float rsel = rng1(rng);
@@ -705,7 +861,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
               const f3 smp = F3(sinTheta * qcosf(phi), sinTheta * qsinf(phi), cosTheta);
               nextDir = toLocalFrame(N, smp);
               bxdf = sampleDiffuse;
-              if (mflags & QA_MTL_HAS_SPECULAR) {
+              if (TEX || (mflags & QA_MTL_HAS_SPECULAR)) {
                 const f3 Ld = normalize(nextDir);
                 const f3 H = normalize(V + Ld);
                 const float cosNH = qmax(0.f, dot(N, H));
@@ -716,26 +872,23 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
             }
           }
 
-          // direct lighting (:481-498): every non-ambient light, weight 1/#lights (ambient counted)
-          if (LIGHTS) {
-            const float normCoefDI = 1.f / (float) sc.num_lights;
-            for (int li = 0; li < sc.num_lights; ++li) {
-              const qa_light &l = sc.light[li];
-              if (l.type == QA_LIGHT_AMBIENT) continue;
-              const f3 intensity = illuminate<RES, STATS>(mem, sc, l, p, stack, cnt) * normCoefDI;
-              const f3 Ld = normalize(-lightDirection(l, p));
-              const f3 H = normalize(V + Ld);
-              const float cosNL = qmax(0.f, dot(N, Ld));
-              const float cosNH = qmax(0.f, dot(N, H));
-              const f3 brdf = sampleDiffuse + sampleSpecular * qpowf(cosNH, glossSpec);
-              path.L = path.L + path.T * ((intensity * cosNL) * brdf);
-            }
+          // direct lighting (:481-498)
+          if (LIGHTS && !AREA) {
+            path.L = path.L + path.T * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng);
+          }
+          if (AREA && nrec < QA_MAX_PATH) {
+            const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, path.T.x, path.T.y, path.T.z,
+                                            sampleDiffuse.x, sampleDiffuse.y, sampleDiffuse.z,
+                                            sampleSpecular.x, sampleSpecular.y, sampleSpecular.z, glossSpec};
+            for (int f = 0; f < QA_REC_FLOATS; ++f) rec[(size_t) (nrec * QA_REC_FLOATS + f) * recStride] = v[f];
+            ++nrec;
           }
 
           if (spawn) {
             // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
             path.ray.p = p;
             path.ray.d = normalize(nextDir);
+            if (TEX) pathDiff.dx = pathDiff.dy = path.ray.d;  // DiffRay(pos, dir): x = y = c (ray.h:57-63)
             path.T = path.T * bxdf;
             path.absorbMtl = mi;
             path.bounce -= 1;
@@ -750,6 +903,16 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
 
     // ---- E. sample finished: SuperSamplerHalton::Accumulate / Loop (scene.cpp:92-121) ---------
     if (alive && done) {
+      if (AREA) {
+        for (int lvl = nrec - 1; lvl >= 0; --lvl) {
+          float v[QA_REC_FLOATS];
+          for (int f = 0; f < QA_REC_FLOATS; ++f) v[f] = rec[(size_t) (lvl * QA_REC_FLOATS + f) * recStride];
+          const f3 d = directLight<RES, STATS>(mem, sc, F3(v[0], v[1], v[2]), F3(v[3], v[4], v[5]), F3(v[6], v[7], v[8]),
+                                               F3(v[12], v[13], v[14]), F3(v[15], v[16], v[17]), v[18], stack, cnt, rng);
+          path.L = path.L + F3(v[9], v[10], v[11]) * d;
+        }
+        nrec = 0;
+      }
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
       f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);

@@ -72,7 +72,9 @@ struct DMesh {
   uint32_t rootData;           // nodes[1].data
   uint32_t stackNeed;          // deepest traversal stack this BVH can require
   // offsets (in 16-byte units) of this mesh's arrays inside the resident image
-  uint32_t resNodes, resTris, resShade, pad;
+  uint32_t resNodes, resTris, resShade;
+  uint32_t hasVT;              // every face carries texture vertices (mixed meshes are refused)
+  const float *vt;             // [6 * num_faces] texture vertices per triangle, element order
 };
 
 struct DCamera {
@@ -90,6 +92,11 @@ struct DScene {
   const DMesh *mesh;
   const float *halton;         // 2 floats per sample index, [halton_count]
   const uint4 *resident;       // resident image (nodes | tris | shade | materials), or nullptr
+  const qa_texmap *texmap;     // TEX variants: tables inside the blob
+  const qa_texture *tex;
+  const float *texFilter;      // 31 x (x, y) elliptical filter taps (src/core/texture.cpp:39-46)
+  float *areaScratch;          // AREA variants: [QA_MAX_PATH * 19][grid threads] hit log
+  const int32_t *mtlTex;       // 8 ints per material: texmap of diffuse, specular, emission, reflection, refraction
   DCamera cam;
   float background[3], environment[3];
   int32_t num_inst, num_lights, halton_count, num_materials;
@@ -98,7 +105,8 @@ struct DScene {
   uint32_t stackNeed;          // max over meshes
   uint32_t rootIdentity;       // instance 0 has tm = itm = I and pos = 0 (always, for XML scenes)
   uint32_t stackDepth;         // entries per lane of the LDS traversal stack
-  uint32_t pad[3];
+  int32_t bgTexmap, envTexmap; // texmaps of the background / environment colours (-1 = none)
+  uint32_t pad;
 };
 
 struct DCounters {

@@ -20,7 +20,8 @@ RMSE_TOL = 1e-6
 MAXABS_TOL = 1e-4
 SUPPORTED = ["c1_sphere_256x256_1spp", "c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp",
              "blinn_48x36_4spp", "box3_48x36_4spp", "project4_48x36_4spp", "glass_48x36_8spp", "glossy_48x36_8spp",
-             "coffee_48x36_4spp_bounce2", "sphere_adaptive_64x48_4to32spp"]
+             "coffee_48x36_4spp_bounce2", "sphere_adaptive_64x48_4to32spp",
+             "textures_80x60_2spp", "softshadow_dof_60x45_2spp"]
 BIT_EXACT = ["c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp"]
 
 
@@ -138,12 +139,41 @@ def test_stop_flag_skips_pixels_and_error_codes(ctx):
     fresh.clear_stop()
     rgb, depth, ns = fresh.render_region((0, 0, 64, 64), 4)
     assert (ns == 4).all()
-    # features the HIP path does not implement yet are refused loudly, never silently approximated
-    for scene in ("custom_textures.xml", "custom_softshadow.xml"):
-        with pytest.raises(hip.HipError) as e:
-            fresh.upload_scene(load_scene_blob(scene))
-        assert e.value.code == -6  # QA_EUNSUPPORTED
+    # what the HIP path cannot reproduce is refused loudly, never silently approximated:
+    # area lights log one record per hit and hold at most 8 (maxBounce <= 7)
+    fresh.upload_scene(load_scene_blob("custom_softshadow.xml"))
+    with pytest.raises(hip.HipError) as e:
+        fresh.render_region((0, 0, 8, 8), 1, max_bounce=9)
+    assert e.value.code == -6  # QA_EUNSUPPORTED
     fresh.close()
+
+
+def test_cli_driver_matches_python_path(tmp_path):
+    """qaray_hip (C++ Renderer + the reference's command line) writes the same colorBuffer.png as the
+    ctypes path through FrameBuffer."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from qaray_amd import hip
+    from qaray_amd.host import FrameBuffer, load_scene_blob, SCENES_DIR
+    exe = os.path.join(ROOT, "qaray_amd", "lib", "qaray_hip")
+    out = str(tmp_path) + "/"
+    r = subprocess.run([exe, "-batch", "-spp", "4", "-size", "96", "64", "-root", SCENES_DIR, "-out", out,
+                        os.path.join(SCENES_DIR, "example_project12_box.xml")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "Elapsed Time is" in r.stdout
+    c = hip.Context(0)
+    c.upload_scene(load_scene_blob("example_project12_box.xml", size=(96, 64)))
+    rgb, depth, ns = c.render_region((0, 0, 96, 64), 4)
+    fb = FrameBuffer(96, 64)
+    fb.deposit(0, 0, 96, 64, rgb, depth, ns, 4, use_srgb=True)
+    ref = str(tmp_path / "py.png")
+    fb.save_image(ref)
+    assert open(out + "colorBuffer.png", "rb").read() == open(ref, "rb").read()
+    for name in ("depthBuffer.png", "sampleBuffer.png"):
+        assert os.path.getsize(out + name) > 100
+    c.close()
 
 
 def test_device_sincos_equals_host_libm(ctx):

@@ -10,7 +10,9 @@ cases = [("example_project12_box.xml", (64, 64), 4), ("example_project3_sphere.x
          ("example_project12_box.xml", (96, 80), 16), ("example_project3_sphere.xml", (100, 75), 8),
          ("example_project2_blinn.xml", (96, 72), 8), ("example_project3_box.xml", (96, 72), 8),
          ("example_project4.xml", (96, 72), 8), ("trc_mtl_glass.xml", (96, 72), 8),
-         ("trc_mtl_glossy.xml", (96, 72), 8), ("trc_mtl_coffee.xml", (96, 72), 8)]
+         ("trc_mtl_glossy.xml", (96, 72), 8), ("trc_mtl_coffee.xml", (96, 72), 8),
+         ("custom_textures.xml", (160, 120), 4), ("custom_textures.xml", (80, 60), 2),
+         ("custom_softshadow.xml", (120, 90), 4), ("custom_softshadow.xml", (60, 45), 2)]
 ctx = hip.Context(0)
 for name, (w, h), spp in cases:
     blob = load_scene_blob(name, size=(w, h))
