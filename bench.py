@@ -42,7 +42,14 @@ def cpu_baseline(scene_xml, width, height, spp, seed):
     sources) timed on this host's cores on a bounded sample of the same workload: the same frame
     at `spp` samples per pixel.  Falls back to the C restatement ("port") when the reference binary
     did not travel."""
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a share of the host (cgroup quota), not every hardware thread
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     sample = f"{os.path.basename(scene_xml)} {width}x{height} at {spp} spp (same frame, fewer spp), seed {seed:#x}"
     if os.path.exists(harness):
@@ -184,11 +191,26 @@ def main():
                        "casts_per_sample": (casts_n + casts_s) / max(samples, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "qa::qa_integrate<false>", "kernel_ms_avg": k_ms, "launches": int(launches),
+                         "kernel": "qa::qa_integrate<RES=1,LIGHTS=0,TEX=0,AREA=0,STATS=0>", "kernel_ms_avg": k_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": k_bytes,
                          "note": "algorithmic bytes = casts x 144 B + samples x 24 B (SURVEY.md 8d); path state "
                                  "actually lives in VGPRs/LDS, so measured HBM traffic is far below this"},
         }
+        # measured HBM traffic of the same launch shape, from the committed rocprofv3 --pmc passes
+        try:
+            prof_dir = os.path.join(ROOT, "profiles")
+            best = None
+            for d in sorted(os.listdir(prof_dir)):
+                for f in sorted(os.listdir(os.path.join(prof_dir, d))):
+                    if f.endswith("_summary.json"):
+                        sj = json.load(open(os.path.join(prof_dir, d, f)))
+                        if sj.get("frame") == [W, H] and sj.get("spp") == args.spp and "hbm_traffic_bytes_per_launch" in sj:
+                            best = (sj, os.path.join("profiles", d, f))
+            if best:
+                out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes)"
+        except Exception:
+            pass
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, args.cpu_spp, args.seed)
         if args.save_png:

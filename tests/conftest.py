@@ -37,8 +37,15 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
 
 
+def ensure_assets():
+    """Synthetic stand-in meshes / textures (scenes/gen_assets.py) are generated on demand."""
+    subprocess.run([sys.executable, os.path.join(ROOT, "scenes", "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
+
+
 def golden_blob(meta):
     from qaray_amd.host import load_scene_blob
+    if meta["scene"] in ("example_project7_object.xml", "example_project12_caustics_glossy.xml", "trc_scene_tower.xml"):
+        ensure_assets()
     return load_scene_blob(meta["scene"], size=(meta["width"], meta["height"]))
 
 

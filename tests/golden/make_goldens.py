@@ -34,11 +34,16 @@ CASES = [
     ("sphere_adaptive_64x48_4to32spp", "example_project3_sphere.xml", (64, 48), None, 4, 32, 5),
     ("textures_80x60_2spp", "custom_textures.xml", (80, 60), None, 2, 2, 5),
     ("softshadow_dof_60x45_2spp", "custom_softshadow.xml", (60, 45), None, 2, 2, 5),
+    # BASELINE configs 2-4 on the synthetic stand-in assets (scenes/gen_assets.py), crops at full size
+    ("c3_object_1080p_crop_2spp", "example_project7_object.xml", (1920, 1080), (840, 560, 888, 592), 2, 2, 5),
+    ("c4_caustics_4k_crop_4spp", "example_project12_caustics_glossy.xml", (3840, 2160), (1900, 1300, 1948, 1332), 4, 4, 5),
+    ("c5_tower_4k_crop_2spp", "trc_scene_tower.xml", (3840, 2160), (1800, 1000, 1848, 1032), 2, 2, 5),
 ]
 SEED = 0x51A7A7
 
 
 def main():
+    subprocess.run([sys.executable, os.path.join(SCENES, "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
     if not os.path.exists(HARNESS):
         sys.exit(f"{HARNESS} missing: run `make -C oracle ref` in the dev container")
     for name, scene, (w, h), crop, smin, smax, bounce in CASES:
