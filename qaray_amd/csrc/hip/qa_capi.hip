@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "qa_kernel.h"
+#include "qa_kernel_sm.h"
 #include "qaray_hip.h"
 
 using namespace qa;
@@ -54,7 +54,10 @@ struct qa_ctx {
   int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
   void (*kernel)(const DScene, const RenderParams) = nullptr;
   void (*kernelStats)(const DScene, const RenderParams) = nullptr;
-  bool resident = false, textured = false, area = false;
+  bool resident = false, textured = false, area = false, useSM = false;
+  int syncAuto = 0;
+  int smGen = 32, smInst = 16, smTrav = 16;
+  int syncSamples = -1;  // -1: decide per scene (SelectKernel), 0/1 forced by QA_SYNC
   uint32_t stackDepth = 32;
   size_t ldsBytes = 0;
 };
@@ -122,6 +125,18 @@ static KernelFn PickShading(bool lights, bool tex, bool area)
   if (lights) return (KernelFn) qa_integrate<RES, true, false, false, STATS>;
   return (KernelFn) qa_integrate<RES, false, false, false, STATS>;
 }
+template <bool RES, bool STATS>
+static KernelFn PickShadingSM(bool lights, bool tex)
+{
+  if (tex) return (KernelFn) qa_integrate_sm<RES, true, true, STATS>;
+  if (lights) return (KernelFn) qa_integrate_sm<RES, true, false, STATS>;
+  return (KernelFn) qa_integrate_sm<RES, false, false, STATS>;
+}
+static KernelFn PickKernelSM(bool resident, bool lights, bool tex, bool stats)
+{
+  if (resident) return stats ? PickShadingSM<true, true>(lights, tex) : PickShadingSM<true, false>(lights, tex);
+  return stats ? PickShadingSM<false, true>(lights, tex) : PickShadingSM<false, false>(lights, tex);
+}
 static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool stats)
 {
   if (resident) return stats ? PickShading<true, true>(lights, tex, area) : PickShading<true, false>(lights, tex, area);
@@ -133,8 +148,21 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
 static int SelectKernel(qa_ctx *c)
 {
   const bool lights = c->ds.num_lights > 0;
-  c->kernel = PickKernel(c->resident, lights, c->textured, c->area, false);
-  c->kernelStats = PickKernel(c->resident, lights, c->textured, c->area, true);
+  // kernel family: the interleaved state machine (suspendable casts) unless the scene has area
+  // lights; QA_KERNEL=lockstep|sm overrides for A/B runs
+  bool sm = false;  // measured slower than the lockstep kernel on every scene so far
+  if (const char *e = getenv("QA_KERNEL")) {
+    if (!strcmp(e, "lockstep")) sm = false;
+    else if (!strcmp(e, "sm") && !c->area) sm = true;
+  }
+  c->useSM = sm;
+  if (sm) {
+    c->kernel = PickKernelSM(c->resident, lights, c->textured, false);
+    c->kernelStats = PickKernelSM(c->resident, lights, c->textured, true);
+  } else {
+    c->kernel = PickKernel(c->resident, lights, c->textured, c->area, false);
+    c->kernelStats = PickKernel(c->resident, lights, c->textured, c->area, true);
+  }
   int resident = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
@@ -321,6 +349,7 @@ static int PrepareScene(qa_ctx *c)
   // ---- material table (plain colours) -----------------------------------------------------------
   const qa_material *mats = QA_BLOB_PTR(qa_material, blob, h->off_materials);
   std::vector<DMaterial> dmat(h->num_materials);
+  bool anySpecularLobes = false;
   for (uint32_t i = 0; i < h->num_materials; ++i) {
     const qa_material &m = mats[i];
     DMaterial &d = dmat[i];
@@ -332,6 +361,7 @@ static int PrepareScene(qa_ctx *c)
     memcpy(d.absorption, m.absorption, 12);
     d.flags = 0;
     for (int k = 0; k < 3; ++k) {
+      if (m.reflection.color[k] != 0.f || m.refraction.color[k] != 0.f) anySpecularLobes = true;
       if (m.reflection.color[k] != 0.f || m.refraction.color[k] != 0.f) d.flags |= QA_MTL_SPECULAR_LOBES;
       if (m.specular.color[k] != 0.f) d.flags |= QA_MTL_HAS_SPECULAR;
     }
@@ -370,6 +400,10 @@ static int PrepareScene(qa_ctx *c)
   ds.envTexmap = h->environment.texmap;
   c->textured = textured;
   c->area = area;
+  // Without reflective / refractive lobes a path is at most camera ray + one diffuse bounce: starting
+  // the samples of a wave together keeps its coherent camera rays apart from the incoherent bounce
+  // rays (+21 % on the Cornell box).  Long specular chains would make lanes wait for the longest path.
+  c->syncAuto = anySpecularLobes ? 0 : 1;
   if (area) {
     // hit log of the AREA variants: QA_MAX_PATH x 19 floats per thread of the largest grid
     const size_t threads = (size_t) c->numCUs * 8 * QA_BLOCK;
@@ -477,6 +511,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   rp.spp_min = spp_min; rp.spp_max = spp_max; rp.max_bounce = max_bounce;
   rp.seed = seed;
   rp.tile_row0 = tile_row0; rp.tile_row_step = tile_row_step; rp.own_tile_rows = ownRows; rp.pad = 0;
+  rp.sync_samples = c->syncSamples < 0 ? c->syncAuto : c->syncSamples;
+  rp.sm_gen_thresh = c->smGen; rp.sm_inst_thresh = c->smInst; rp.sm_trav_steps = c->smTrav;
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
   rp.stop_flag = c->dStopAlias;
@@ -580,6 +616,10 @@ int qa_ctx_create(int device_id, qa_ctx **out)
     return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
   }
   *c->hStop = 0;
+  if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
+  if (const char *e = getenv("QA_SM_GEN")) c->smGen = atoi(e);
+  if (const char *e = getenv("QA_SM_INST")) c->smInst = atoi(e);
+  if (const char *e = getenv("QA_SM_TRAV")) c->smTrav = atoi(e) > 0 ? atoi(e) : 1;
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));

@@ -814,7 +814,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
     if (!__any(alive)) break;
 
     // ---- B. start a sample: camera ray (src/renderers/renderer.cpp:312-328) ------------------
-    if (alive && needSample) {
+    // sync_samples: lanes wait until the whole wave is between samples, so that the coherent
+    // camera rays of a tile are traced together instead of next to incoherent secondary rays
+    const bool goSample = !rp.sync_samples || (__ballot(needSample) == __ballot(alive && !needPixel));
+    if (alive && needSample && goSample) {
       const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
       texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
 
     // ---- C. trace ----------------------------------------------------------------------------
     bool done = false;  // path finished in this iteration
-    if (alive && !needPixel) {
+    if (alive && !needPixel && !needSample) {
       Hit h;
       h.z = QA_BIGFLOAT;
       h.node = -1;

@@ -118,6 +118,8 @@ struct RenderParams {
   int32_t spp_min, spp_max, max_bounce;
   uint32_t seed;
   int32_t tile_row0, tile_row_step, own_tile_rows, pad;  // which 8-row strips of the region
+  int32_t sm_gen_thresh, sm_inst_thresh, sm_trav_steps;
+  int32_t sync_samples;        // 1: a wave starts its lanes' next samples together (coherent primary rays)  // scheduling knobs of qa_integrate_sm
   float *rgb;                  // region-local outputs
   float *depth;
   uint32_t *ns;
