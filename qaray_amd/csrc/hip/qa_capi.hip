@@ -2,6 +2,7 @@
 // upload (blob -> device tables), launches of the integrator kernel, counters and timing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -56,6 +57,8 @@ struct qa_ctx {
   void (*kernelStats)(const DScene, const RenderParams) = nullptr;
   bool resident = false, textured = false, area = false, useSM = false;
   int syncAuto = 0;
+  uint32_t *dOrder = nullptr;   // tile launch order of the last region shape
+  uint64_t orderKey = 0;
   int smGen = 32, smInst = 16, smTrav = 16;
   int syncSamples = -1;  // -1: decide per scene (SelectKernel), 0/1 forced by QA_SYNC
   uint32_t stackDepth = 32;
@@ -515,6 +518,33 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   rp.sm_gen_thresh = c->smGen; rp.sm_inst_thresh = c->smInst; rp.sm_trav_steps = c->smTrav;
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
+  rp.tile_order = nullptr;
+  {
+    // Tiles are handed out centre-first: the cheap ones (rays that leave the scene at the image
+    // border) end up last, so the end-of-frame tail is made of short tiles instead of long ones.
+    const int tx = (x1 - x0 + 7) / 8;
+    const uint64_t key = ((uint64_t) tx << 40) ^ ((uint64_t) ownRows << 20) ^ ((uint64_t) tile_row0 << 8) ^ (uint64_t) tile_row_step ^
+                         ((uint64_t) (y1 - y0) << 50);
+    if (key != c->orderKey || !c->dOrder) {
+      const size_t n = (size_t) tx * ownRows;
+      std::vector<std::pair<float, uint32_t>> v(n);
+      const float cx = 0.5f * (x1 - x0), cy = 0.5f * (y1 - y0);
+      for (int r = 0; r < ownRows; ++r)
+        for (int i = 0; i < tx; ++i) {
+          const float px = i * 8 + 4 - cx, py = (tile_row0 + r * tile_row_step) * 8 + 4 - cy;
+          v[(size_t) r * tx + i] = {px * px + py * py, (uint32_t) (r * tx + i)};
+        }
+      std::stable_sort(v.begin(), v.end(), [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) { return a.first < b.first; });
+      std::vector<uint32_t> order(n);
+      for (size_t i = 0; i < n; ++i) order[i] = v[i].second;
+      if (c->dOrder) { HIP_TRY(hipStreamSynchronize(s)); (void) hipFree(c->dOrder); c->dOrder = nullptr; }
+      HIP_TRY(hipMalloc((void **) &c->dOrder, n * sizeof(uint32_t)));
+      HIP_TRY(hipMemcpyAsync(c->dOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      c->orderKey = key;
+    }
+    if (!getenv("QA_NO_TILE_ORDER")) rp.tile_order = c->dOrder;
+  }
   rp.stop_flag = c->dStopAlias;
   rp.counters = c->dCounters;
 
@@ -637,6 +667,7 @@ int qa_ctx_destroy(qa_ctx *c)
   for (EventPair &ev : c->pending) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
   for (EventPair &ev : c->freeEvents) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
   if (c->dHalton) (void) hipFree(c->dHalton);
+  if (c->dOrder) (void) hipFree(c->dOrder);
   if (c->dWork) (void) hipFree(c->dWork);
   if (c->dCounters) (void) hipFree(c->dCounters);
   if (c->hStop) (void) hipHostFree(c->hStop);

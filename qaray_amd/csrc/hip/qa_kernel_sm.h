@@ -125,7 +125,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
             mode = SM_IDLE;
           } else {
             const unsigned w = base + lane;
-            const unsigned tile = w / 64, in = w % 64;
+            const unsigned in = w % 64;
+            const unsigned tile = rp.tile_order ? rp.tile_order[w / 64] : w / 64;
             const unsigned otr = tile / tilesX;
             const unsigned tx = (tile % tilesX) * 8 + (in % 8);
             const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);

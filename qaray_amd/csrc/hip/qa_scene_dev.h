@@ -123,6 +123,7 @@ struct RenderParams {
   float *rgb;                  // region-local outputs
   float *depth;
   uint32_t *ns;
+  const uint32_t *tile_order;  // launch order of the tiles (centre of the region first), or nullptr
   unsigned int *work_counter;  // next work item (pixel) of this launch
   const volatile int *stop_flag;
   DCounters *counters;
