@@ -88,6 +88,11 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x51A7A7)
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--save-png", default=None, help="rank 0: write the last frame through FrameBuffer")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, "
+                         "collectives go through host memory)")
+    ap.add_argument("--check", action="store_true",
+                    help="rank 0: also render the whole frame alone and require the gathered image to equal it bit for bit")
     args = ap.parse_args()
 
     import torch
@@ -102,10 +107,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
+    coll_device = device if args.backend == "nccl" else torch.device("cpu")
 
     W, H = frame_size(world, args.width, args.height)
     scene_xml = args.scene if os.path.isabs(args.scene) else os.path.join(SCENES_DIR, args.scene)
@@ -114,7 +125,7 @@ def main():
     # rank 0 parses + flattens; everyone receives the blob over RCCL and adopts it from HBM
     blob = load_scene_blob(scene_xml, size=(W, H)) if rank == 0 else None
     if world > 1:
-        dblob = qd.broadcast_blob(blob, device, src=0)
+        dblob = qd.broadcast_blob(blob, coll_device, src=0).to(device)
     else:
         dblob = torch.from_numpy(blob).to(device)
     ctx.upload_scene_device(dblob)
@@ -135,7 +146,7 @@ def main():
             ctx.render_strips_device((0, 0, W, H), rank, world, args.spp, rgb[:nown], depth[:nown], ns[:nown],
                                      max_bounce=args.bounce, seed=args.seed, stream=stream)
         if world > 1:
-            g = qd.gather_packed(rgb, dst=0)
+            g = qd.gather_packed(rgb if args.backend == "nccl" else rgb.cpu(), dst=0)
             if rank == 0:
                 full = qd.assemble(g, H, world)
         else:
@@ -158,13 +169,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     kernel_ms, launches = ctx.kernel_time()
     cnt = ctx.counters()
-    local = torch.tensor([cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]], dtype=torch.float64, device=device)
+    local = torch.tensor([cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
     samples, casts_n, casts_s = (float(v) for v in local.tolist())
@@ -213,6 +224,9 @@ def main():
             pass
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, args.cpu_spp, args.seed)
+        if args.check:
+            alone = ctx.render_region((0, 0, W, H), args.spp, max_bounce=args.bounce, seed=args.seed)[0]
+            out["check"] = bool(np.array_equal(alone.view(np.uint32), full.cpu().numpy().view(np.uint32)))
         if args.save_png:
             fb = FrameBuffer(W, H)
             fb.deposit(0, 0, W, H, full.cpu().numpy(), np.zeros((H, W), np.float32),

@@ -197,3 +197,24 @@ def test_device_sincos_equals_host_libm(ctx):
     hs = np.array([libm.sinf(float(v)) for v in x[idx]], np.float32)
     hc = np.array([libm.cosf(float(v)) for v in x[idx]], np.float32)
     assert np.array_equal(bits(s[idx]), bits(hs)) and np.array_equal(bits(c[idx]), bits(hc))
+
+
+def test_two_rank_bench_rehearsal_equals_single_rank():
+    """bench.py's N>1 path (blob broadcast, round-robin strips, gather, assemble) with two ranks that
+    share this box's GPU (gloo transport; the nccl path differs only in where the collectives run)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check",
+           "--steps", "1", "--warmup", "0", "--spp", "4", "--width", "320", "--height", "180", "--cpu-spp", "0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["check"] is True
+    assert d["config"]["frame"] == [453, 255]   # 320x180 scaled by sqrt(2): weak scaling in resolution
