@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--bounce", type=int, default=5)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x51A7A7)
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--save-png", default=None, help="rank 0: write the last frame through FrameBuffer")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, "
