@@ -446,13 +446,16 @@ static int PrepareScene(qa_ctx *c)
   const size_t stackBytes = ((size_t) c->stackDepth + 6) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = image.size() * sizeof(uint4);
   if (stackBytes > kMaxLdsPerBlock) return Fail(QA_EUNSUPPORTED, "BVH too deep for the LDS traversal stack");
-  c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget);
+  c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget &&
+                 h->num_instances <= QA_KARG_INST && h->num_meshes <= QA_KARG_MESH);
   if (c->resident) {
     const uint4 *dimg = nullptr;
     if ((rc = DeviceCopy(c, image, &dimg)) != QA_OK) return rc;
     ds.resident = dimg;
     ds.residentVec4 = (uint32_t) image.size();
     ds.resMaterials = resMaterials;
+    for (uint32_t k = 0; k < h->num_instances; ++k) ds.instv[k] = inst[k];
+    for (uint32_t k = 0; k < h->num_meshes; ++k) ds.meshv[k] = dmeshes[k];
   }
   c->ldsBytes = stackBytes + (c->resident ? imageBytes : 0);
   memcpy(ds.cam.screenA, h->screenA, 12);

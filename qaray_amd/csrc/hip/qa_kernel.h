@@ -63,6 +63,23 @@ struct SceneMem {
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
+// Scene-graph nodes and mesh descriptors: resident scenes carry them BY VALUE in the kernel
+// arguments (constant address space: wave-uniform indices become scalar loads into SGPRs, no
+// vector-memory round trip on the critical path of every cast); larger scenes read the tables
+// from global memory.
+template <bool RES>
+__device__ __forceinline__ const qa_instance &instAt(const DScene &sc, int k)
+{
+  if constexpr (RES) return sc.instv[k];
+  else return sc.inst[k];
+}
+template <bool RES>
+__device__ __forceinline__ const DMesh &meshAt(const DScene &sc, int k)
+{
+  if constexpr (RES) return sc.meshv[k];
+  else return sc.mesh[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 // RNG: Sampler_Marsaglia::xorshift32 (src/samplers/Sampler_Marsaglia.cpp:43-53)
 // ---------------------------------------------------------------------------------------------
@@ -119,6 +136,7 @@ __device__ __forceinline__ f3 toNodeDir(const qa_instance &in, f3 beforeP, f3 af
 {
   return mulMV(in.itm, (beforeP + dir) - ld3(in.pos)) - afterP;
 }
+template <bool RES>
 __device__ __forceinline__ void localRayDiff(const DScene &sc, int k, const Ray &world, const RayDiff &wd, Ray &r, RayDiff &rd)
 {
   // root level
@@ -130,15 +148,15 @@ __device__ __forceinline__ void localRayDiff(const DScene &sc, int k, const Ray 
     cd.dx = (world.p + wd.dx) - world.p;
     cd.dy = (world.p + wd.dy) - world.p;
   } else {
-    cur = toNode(sc.inst[0], world);
-    cd.dx = toNodeDir(sc.inst[0], world.p, cur.p, wd.dx);
-    cd.dy = toNodeDir(sc.inst[0], world.p, cur.p, wd.dy);
+    cur = toNode(instAt<RES>(sc, 0), world);
+    cd.dx = toNodeDir(instAt<RES>(sc, 0), world.p, cur.p, wd.dx);
+    cd.dy = toNodeDir(instAt<RES>(sc, 0), world.p, cur.p, wd.dy);
   }
   int chain[QA_MAX_NODE_DEPTH];
   int n = 0;
-  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = sc.inst[a].parent) chain[n++] = a;
+  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = instAt<RES>(sc, a).parent) chain[n++] = a;
   for (int q = n - 1; q >= 0; --q) {
-    const qa_instance &in = sc.inst[chain[q]];
+    const qa_instance &in = instAt<RES>(sc, chain[q]);
     const Ray nx = toNode(in, cur);
     cd.dx = toNodeDir(in, cur.p, nx.p, cd.dx);
     cd.dy = toNodeDir(in, cur.p, nx.p, cd.dy);
@@ -152,9 +170,10 @@ __device__ __forceinline__ void localRayDiff(const DScene &sc, int k, const Ray 
 // tm = itm = I, pos = 0.  Multiplying by the identity and subtracting zero return their operand
 // (up to the sign of a zero), so Node::ToNodeCoords at the root reduces to dir' = (p + dir) - p,
 // whose two roundings are what the reference performs and must be kept.
+template <bool RES>
 __device__ __forceinline__ Ray rootRay(const DScene &sc, const Ray &world)
 {
-  if (!sc.rootIdentity) return toNode(sc.inst[0], world);
+  if (!sc.rootIdentity) return toNode(instAt<RES>(sc, 0), world);
   Ray o;
   o.p = world.p;
   o.d = (world.p + world.d) - world.p;
@@ -163,15 +182,16 @@ __device__ __forceinline__ Ray rootRay(const DScene &sc, const Ray &world)
 
 // Local ray of instance k: the root's transform has already been applied (r0); walk the rest of
 // the ancestor chain top-down.  All lanes work on the same k, so the chain is wave-uniform.
+template <bool RES>
 __device__ __forceinline__ Ray localRay(const DScene &sc, int k, const Ray &r0)
 {
-  const int depth = sc.inst[k].depth;
-  if (depth == 1) return toNode(sc.inst[k], r0);
+  const int depth = instAt<RES>(sc, k).depth;
+  if (depth == 1) return toNode(instAt<RES>(sc, k), r0);
   int chain[QA_MAX_NODE_DEPTH];
   int n = 0;
-  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = sc.inst[a].parent) chain[n++] = a;
+  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = instAt<RES>(sc, a).parent) chain[n++] = a;
   Ray r = r0;
-  for (int q = n - 1; q >= 0; --q) r = toNode(sc.inst[chain[q]], r);
+  for (int q = n - 1; q >= 0; --q) r = toNode(instAt<RES>(sc, chain[q]), r);
   return r;
 }
 
@@ -406,15 +426,15 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
                                              Hit &h, TexHit &th, uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_normal++;
-  const Ray r0 = rootRay(sc, world);
+  const Ray r0 = rootRay<RES>(sc, world);
   bool any = false;
   for (int k = 1; k < sc.num_inst; ++k) {
-    const int type = sc.inst[k].obj_type;
+    const int type = instAt<RES>(sc, k).obj_type;
     if (type == QA_OBJ_NONE) continue;
     Ray r;
     RayDiff rd;
-    if (TEX) localRayDiff(sc, k, world, wd, r, rd);
-    else r = localRay(sc, k, r0);
+    if (TEX) localRayDiff<RES>(sc, k, world, wd, r, rd);
+    else r = localRay<RES>(sc, k, r0);
     bool hit;
     if (type == QA_OBJ_SPHERE) {
       hit = hitSphere(r, h, k, true);
@@ -423,7 +443,7 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
       hit = hitPlane(r, h, k, true);
       if (TEX && hit) texPlane(r.p, rd.dx, rd.dy, h.p, th);
     } else {
-      const DMesh &m = sc.mesh[sc.inst[k].mesh];
+      const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
       TriPick pick;
       hit = hitMesh<RES, STATS>(mem, m, r, h, k, true, stack, cnt, pick);
       if (TEX && hit && m.hasVT) {
@@ -437,12 +457,12 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
   if (any) {
     // Node::FromNodeCoords at every level from the hit node up to and including the root
     // (src/core/node.cpp:127-139); the reference applies them as its recursion unwinds.
-    for (int a = h.node; a >= 0; a = sc.inst[a].parent) {
+    for (int a = h.node; a >= 0; a = instAt<RES>(sc, a).parent) {
       if (a == 0 && sc.rootIdentity) {
         h.N = normalize(h.N);  // identity root: p unchanged, the normal is still re-normalised
         break;
       }
-      const qa_instance &in = sc.inst[a];
+      const qa_instance &in = instAt<RES>(sc, a);
       h.p = mulMV(in.tm, h.p) + ld3(in.pos);
       h.N = normalize(mulTMV(in.itm, h.N));
     }
@@ -459,17 +479,17 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
   Hit h;
   h.z = t_max;
   h.node = -1;
-  const Ray r0 = rootRay(sc, world);
+  const Ray r0 = rootRay<RES>(sc, world);
   for (int k = 1; k < sc.num_inst; ++k) {
-    const int type = sc.inst[k].obj_type;
+    const int type = instAt<RES>(sc, k).obj_type;
     if (type == QA_OBJ_NONE) continue;
-    const Ray r = localRay(sc, k, r0);
+    const Ray r = localRay<RES>(sc, k, r0);
     bool hit;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
     else {
       TriPick pick;
-      hit = hitMesh<RES, STATS>(mem, sc.mesh[sc.inst[k].mesh], r, h, k, false, stack, cnt, pick);
+      hit = hitMesh<RES, STATS>(mem, meshAt<RES>(sc, instAt<RES>(sc, k).mesh), r, h, k, false, stack, cnt, pick);
     }
     if (hit) return 0.0f;
   }
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
           const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
           path.T = path.T * att;
         }
-        const qa_instance &in = sc.inst[h.node];
+        const qa_instance &in = instAt<RES>(sc, h.node);
         int mi = -1;
         bool white = false;
         if (in.mtlset >= 0) {

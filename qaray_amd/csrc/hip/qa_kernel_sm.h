@@ -27,11 +27,12 @@ namespace qa {
 enum { SM_IDLE = 0, SM_WAITPIX = 1, SM_GEN = 2, SM_INST = 3, SM_TRAV = 4 };
 
 // Node::FromNodeCoords up the hit node's ancestry (src/core/node.cpp:127-139)
+template <bool RES>
 __device__ __forceinline__ void hitToWorld(const DScene &sc, Hit &h)
 {
-  for (int a = h.node; a >= 0; a = sc.inst[a].parent) {
+  for (int a = h.node; a >= 0; a = instAt<RES>(sc, a).parent) {
     if (a == 0 && sc.rootIdentity) { h.N = normalize(h.N); break; }
-    const qa_instance &in = sc.inst[a];
+    const qa_instance &in = instAt<RES>(sc, a);
     h.p = mulMV(in.tm, h.p) + ld3(in.pos);
     h.N = normalize(mulTMV(in.itm, h.N));
   }
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
                   const uint4 ab = mtlTable[6 * (size_t) absorbMtl + 5];
                   T = T * F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
                 }
-                const qa_instance &in = sc.inst[h.node];
+                const qa_instance &in = instAt<RES>(sc, h.node);
                 int mi = -1;
                 bool white = false;
                 if (in.mtlset >= 0) {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
           if (start) {
             // arm the cast: Scene::TraceNodeNormal / TraceNodeShadow start at the root's first child
             k = 1;
-            while (k < sc.num_inst && sc.inst[k].obj_type == QA_OBJ_NONE) ++k;
+            while (k < sc.num_inst && instAt<RES>(sc, k).obj_type == QA_OBJ_NONE) ++k;
             h.node = -1;
             occluded = false;
             if (!castShadow) {
@@ -350,14 +351,14 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
       if (nI > 0 && (nI >= instThresh || nT == 0)) {
         if (mode == SM_INST) {
           if (k < sc.num_inst) {
-            const qa_instance &in = sc.inst[k];
+            const qa_instance &in = instAt<RES>(sc, k);
             Ray r;
             RayDiff rd;
-            if (TEX && !castShadow) localRayDiff(sc, k, ray, wd, r, rd);
-            else r = localRay(sc, k, rootRay(sc, ray));
+            if (TEX && !castShadow) localRayDiff<RES>(sc, k, ray, wd, r, rd);
+            else r = localRay<RES>(sc, k, rootRay<RES>(sc, ray));
             const int type = in.obj_type;
             if (type == QA_OBJ_MESH) {
-              const DMesh &m = sc.mesh[in.mesh];
+              const DMesh &m = meshAt<RES>(sc, in.mesh);
               const f3 rc = F3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
               float entry, exit_;
               boxEntryExit(r, rc, ld3(m.bmin), ld3(m.bmax), entry, exit_);
@@ -387,9 +388,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
           }
           if (mode == SM_INST) {
             // object-less nodes only contribute their transforms (through their children's chains)
-            while (k < sc.num_inst && sc.inst[k].obj_type == QA_OBJ_NONE) ++k;
+            while (k < sc.num_inst && instAt<RES>(sc, k).obj_type == QA_OBJ_NONE) ++k;
             if (k >= sc.num_inst) {
-              if (!castShadow && h.node >= 0) hitToWorld(sc, h);
+              if (!castShadow && h.node >= 0) hitToWorld<RES>(sc, h);
               castDone = true;
               mode = SM_GEN;
             }
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
           const bool fastSlab = !__any(inner && degenerate);
           if (inner) {
             if (STATS) cnt.bvh_nodes++;
-            const DMesh &m = sc.mesh[sc.inst[k].mesh];
+            const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
             const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
             const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
             const uint4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
         // ---- leaves ---------------------------------------------------------------------------------------
         if (inTrav && mode == SM_TRAV && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE) {
           if (STATS) cnt.bvh_nodes++;
-          const DMesh &m = sc.mesh[sc.inst[k].mesh];
+          const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
           const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
           const uint32_t count = ((cur >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
           const uint32_t first = cur & QA_BVH_OFFSET_MASK;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
           if (meshHit) {
             if (castShadow) { occluded = true; k = sc.num_inst; }
             else {
-              const DMesh &m = sc.mesh[sc.inst[k].mesh];
+              const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
               const uint4 *s = (RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade)) + 3 * (size_t) pick.tri;
               const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
               const float bc = 1.f - pick.a - pick.b;
@@ -476,9 +477,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
             }
           }
           ++k;
-          while (k < sc.num_inst && sc.inst[k].obj_type == QA_OBJ_NONE) ++k;
+          while (k < sc.num_inst && instAt<RES>(sc, k).obj_type == QA_OBJ_NONE) ++k;
           if (k >= sc.num_inst) {
-            if (!castShadow && h.node >= 0) hitToWorld(sc, h);
+            if (!castShadow && h.node >= 0) hitToWorld<RES>(sc, h);
             castDone = true;
             mode = SM_GEN;
           } else mode = SM_INST;

@@ -77,6 +77,9 @@ struct DMesh {
   const float *vt;             // [6 * num_faces] texture vertices per triangle, element order
 };
 
+#define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
+#define QA_KARG_MESH 4
+
 struct DCamera {
   float screenA[3], screenU[3], screenV[3], screenX[3], screenY[3], pos[3];
   float dof;
@@ -107,6 +110,9 @@ struct DScene {
   uint32_t stackDepth;         // entries per lane of the LDS traversal stack
   int32_t bgTexmap, envTexmap; // texmaps of the background / environment colours (-1 = none)
   uint32_t pad;
+  // resident scenes only: the tables themselves, in the kernel-argument segment
+  qa_instance instv[QA_KARG_INST];
+  DMesh meshv[QA_KARG_MESH];
 };
 
 struct DCounters {
