@@ -83,7 +83,7 @@ def test_flattened_scene_equals_reference_loader(name):
         assert np.array_equal(mine["itm"], np.array(n["itm"], np.uint32)), n["name"]
         assert np.array_equal(mine["pos"], np.array(n["pos"], np.uint32)), n["name"]
         assert mine["parent"] == r["parent"] and mine["depth"] == r["depth"] and mine["subtree_end"] == r["subtree_end"]
-        if n["type"] == "obj" and n["mesh"] < 0:
+        if n["type"] == "none" and n["name"].endswith(".obj"):
             # the dump was taken without the (absent) trc2017 assets: the reference left the node
             # object-less; here it is object-less too unless scenes/gen_assets.py has since run
             assert mine["obj_type"] in (0, 3)
