@@ -329,6 +329,54 @@ __device__ __forceinline__ bool hitTriangle(const uint4 q0, const uint4 q1, cons
   return ok;
 }
 
+// The same test reduced to what the traversal itself needs: accept / reject and the distance.
+// The hit point, facing and barycentrics of the finally accepted triangle are recomputed once per
+// mesh by triangleDetails() with the very same expressions (t is the stored h.z), instead of being
+// carried through seven conditional moves on every one of the ~20 tests of a cast.
+__device__ __forceinline__ bool hitTriangleZ(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, float &hz)
+{
+  const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
+  const f3 A = F3(asF(q0.w), asF(q1.x), asF(q1.y));
+  const float dz = dot(ray.d, N);
+  const float pz = dot(ray.p - A, N);
+  const float t = -pz / dz;
+  bool ok = !(qabs(dz) < 1e-7f) && !(t <= QA_BIAS) && (hz > t);
+  const uint32_t axis = q2.w;
+  const f3 p = ray.p + ray.d * t;
+  const bool ax0 = (axis == 0), ax2 = (axis == 2);
+  const float pu = ax0 ? p.y : p.x;
+  const float pv = ax2 ? p.y : p.z;
+  const float au = ax0 ? A.y : A.x;
+  const float av = ax2 ? A.y : A.z;
+  const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
+  const float a = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
+  const float b = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
+  const float c = 1.f - a - b;
+  ok = ok && !(a < 0 || b < 0 || c < 0);
+  if (ok) hz = t;
+  return ok;
+}
+__device__ __forceinline__ void triangleDetails(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, Hit &h,
+                                                float &ba, float &bb)
+{
+  const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
+  const f3 A = F3(asF(q0.w), asF(q1.x), asF(q1.y));
+  const float dz = dot(ray.d, N);
+  const float t = h.z;
+  const uint32_t axis = q2.w;
+  const f3 p = ray.p + ray.d * t;
+  const bool ax0 = (axis == 0), ax2 = (axis == 2);
+  const float pu = ax0 ? p.y : p.x;
+  const float pv = ax2 ? p.y : p.z;
+  const float au = ax0 ? A.y : A.x;
+  const float av = ax2 ? A.y : A.z;
+  const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
+  ba = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
+  bb = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
+  h.p = p;
+  h.front = (dz <= 0);
+}
+
 // TriObj::IntersectRay + TraceBVHNode (src/objects/objects.cpp:310-420).  The traversal stack
 // holds node DATA words (leaf flag + range, or child index) instead of ids: the word arrives with
 // the node's box when the parent tests its two children, so an inner visit is a single 64-byte
@@ -393,7 +441,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     for (uint32_t i = 0; i < count; ++i) {
       if (STATS) cnt.tri_tests++;
       const uint4 *t = tris + 3 * (size_t) (first + i);
-      if (hitTriangle(t[0], t[1], t[2], ray, h, ba, bb)) {
+      if (hitTriangleZ(t[0], t[1], t[2], ray, h.z)) {
         hasHit = true;
         bestTri = first + i;
         if (!closest) return true;
@@ -402,6 +450,10 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
   }
   if (hasHit && closest) {
+    {
+      const uint4 *t = tris + 3 * (size_t) bestTri;
+      triangleDetails(t[0], t[1], t[2], ray, h, ba, bb);
+    }
     // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
     const uint4 *s = (RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade)) + 3 * (size_t) bestTri;
     const uint4 s0 = s[0], s1 = s[1], s2 = s[2];

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
           for (uint32_t i = 0; i < count && !stop; ++i) {
             if (STATS) cnt.tri_tests++;
             const uint4 *t = tris + 3 * (size_t) (first + i);
-            if (hitTriangle(t[0], t[1], t[2], lr, h, pick.a, pick.b)) {
+            if (hitTriangleZ(t[0], t[1], t[2], lr, h.z)) {
               meshHit = true;
               pick.tri = first + i;
               if (castShadow) stop = true;
@@ -462,6 +462,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_sm(const 
             if (castShadow) { occluded = true; k = sc.num_inst; }
             else {
               const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
+              {
+                const uint4 *t = (RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris)) + 3 * (size_t) pick.tri;
+                triangleDetails(t[0], t[1], t[2], lr, h, pick.a, pick.b);
+              }
               const uint4 *s = (RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade)) + 3 * (size_t) pick.tri;
               const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
               const float bc = 1.f - pick.a - pick.b;
