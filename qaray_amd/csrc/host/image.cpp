@@ -234,6 +234,7 @@ bool LoadPNG(const char *filename, int &width, int &height, std::vector<unsigned
     pos += 12 + len;
   }
   if (!haveHdr || width <= 0 || height <= 0) return fail("missing IHDR");
+  if ((unsigned long long) width * (unsigned long long) height > (1ull << 28)) return fail("image too large");
   if (interlace) return fail("interlaced PNG not supported");
   int channels;
   switch (ctype) {
@@ -370,6 +371,15 @@ bool LoadPPM(const char *filename, int &width, int &height, std::vector<unsigned
     while (ok && line[0] == '#') ok = readLine();
   }
   if (ok && width > 0 && height > 0) {
+    // never allocate more than the file can hold
+    const long here = ftell(fp);
+    fseek(fp, 0, SEEK_END);
+    const long left = ftell(fp) - here;
+    fseek(fp, here, SEEK_SET);
+    if ((unsigned long long) width * (unsigned long long) height * 3ull > (unsigned long long) (left < 0 ? 0 : left)) {
+      fclose(fp);
+      return false;
+    }
     rgb.assign((size_t) width * height * 3, 0);
     const size_t got = fread(rgb.data(), 3, (size_t) width * height, fp);
     (void) got;

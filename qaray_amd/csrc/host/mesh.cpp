@@ -278,6 +278,20 @@ bool TriObj::LoadFromFileObj(const char *filename, std::string *err)
     }
     // g / o / s / t and unknown statements do not change the face order
   }
+  // tinyobjloader does not range-check indices (the reference would read out of bounds); refuse
+  // such files instead
+  {
+    const int nv = (int) (vertices.size() / 3), nn = (int) (normals.size() / 3), nt = (int) (texcoords.size() / 2);
+    for (const qa_face &f : faces)
+      for (int k = 0; k < 3; ++k) {
+        const bool bad = f.v[k] < 0 || f.v[k] >= nv || f.vn[k] < -1 || f.vn[k] >= nn || f.vt[k] < -1 || f.vt[k] >= nt ||
+                         (nn > 0 && f.vn[k] < 0);
+        if (bad) {
+          if (err) *err = "face references a vertex / normal / texture vertex that does not exist";
+          return false;
+        }
+      }
+  }
   // TriMesh.cpp:107-114: faces are ordered by material with std::sort and this comparator; the
   // sort is not stable, so the same library routine is used to land on the same permutation.
   std::sort(faces.begin(), faces.end(), [](const qa_face &a, const qa_face &b) {
