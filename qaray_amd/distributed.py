@@ -62,11 +62,31 @@ def gather_packed(packed, dst=0):
     return out
 
 
+_ROW_INDEX_CACHE = {}
+
+
+def strip_rows(height, world, rank, device=None):
+    """Image rows covered by `rank`'s packed strips, in packed order (torch int64 tensor)."""
+    import torch
+    key = (height, world, rank, str(device))
+    if key not in _ROW_INDEX_CACHE:
+        rows = []
+        for s in own_strips(height, world, rank):
+            r0 = s * STRIP_ROWS
+            rows.extend(range(r0, min(height, r0 + STRIP_ROWS)))
+        _ROW_INDEX_CACHE[key] = torch.tensor(rows, dtype=torch.int64, device=device)
+    return _ROW_INDEX_CACHE[key]
+
+
 def assemble(gathered, height, world):
-    """Rank 0: list of packed per-rank tensors -> full image tensor [height, ...]."""
+    """Rank 0: list of packed per-rank tensors -> full image tensor [height, ...].  One scatter of
+    rows per rank: only the last strip of the image can be ragged, and it is the last strip of its
+    owner's packed buffer, so a rank's valid rows are a prefix of that buffer."""
     import torch
     first = gathered[0]
     full = torch.empty((height,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
     for r in range(world):
-        place_strips(full, gathered[r], height, world, r)
+        idx = strip_rows(height, world, r, first.device)
+        if idx.numel():
+            full.index_copy_(0, idx, gathered[r][:idx.numel()])
     return full
