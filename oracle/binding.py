@@ -18,6 +18,24 @@ class Counters(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("tri_tests", C.c_uint64)]
 
 
+class PhotonMapParams(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("bounce", C.c_uint32), ("radius", C.c_float)]
+
+
+class PhotonParams(C.Structure):
+    _fields_ = [("photon", PhotonMapParams), ("caustics", PhotonMapParams)]
+
+
+# include/qa_photon.h qa_photon (24 bytes)
+PHOTON_DTYPE = np.dtype([("pos", np.float32, 3), ("power", np.float32), ("rgb", np.uint8, 3), ("plane_dirz", np.uint8),
+                         ("dirx", np.int16), ("diry", np.int16)])
+
+
+def photon_params(photon=(10000, 20, 0.2), caustics=(1000, 20, 1.0)):
+    """(size, bounce, radius) per map; defaults = RendererParam (src/renderers/renderer.h:51-57)."""
+    return PhotonParams(PhotonMapParams(*photon), PhotonMapParams(*caustics))
+
+
 _lib = None
 
 
@@ -33,6 +51,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.qa_oracle_render.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_void_p, C.c_void_p,
                                                                        C.c_void_p, C.c_int, C.POINTER(Counters)]
+        L.qa_oracle_render_pm.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_uint32, C.c_void_p, C.c_void_p,
+                                                                          C.c_void_p, C.c_int, C.POINTER(Counters),
+                                                                          C.POINTER(PhotonParams), C.c_void_p, C.c_void_p]
+        L.qa_oracle_photon_build.argtypes = [C.c_void_p, C.POINTER(PhotonParams), C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.qa_oracle_halton.argtypes = [C.c_int, C.c_int]
         L.qa_oracle_halton.restype = C.c_float
         L.qa_oracle_rng_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
@@ -41,8 +64,22 @@ def lib():
     return _lib
 
 
-def render(blob, region, spp, max_bounce=5, seed=0x51A7A7, threads=0, spp_max=None):
-    """blob: numpy uint8 flat scene; region (x0,y0,x1,y1) -> (rgb[h,w,3], depth[h,w], ns[h,w], Counters)."""
+def photon_build(blob, pp, seed=0x51A7A7):
+    """-> (photon[size+1], caustics[size+1]) balanced qa_photon arrays ([0] unused), emitted[2], emissions[2]."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    pm = np.zeros(pp.photon.size + 1, PHOTON_DTYPE)
+    cm = np.zeros(pp.caustics.size + 1, PHOTON_DTYPE)
+    emitted = (C.c_uint64 * 2)()
+    emissions = (C.c_uint64 * 2)()
+    rc = lib().qa_oracle_photon_build(blob.ctypes.data, C.byref(pp), seed, pm.ctypes.data, cm.ctypes.data, emitted, emissions)
+    if rc != 0:
+        raise RuntimeError(f"qa_oracle_photon_build failed: {rc}")
+    return pm, cm, list(emitted), list(emissions)
+
+
+def render(blob, region, spp, max_bounce=5, seed=0x51A7A7, threads=0, spp_max=None, photon=None):
+    """blob: numpy uint8 flat scene; region (x0,y0,x1,y1) -> (rgb[h,w,3], depth[h,w], ns[h,w], Counters).
+    photon: (PhotonParams, photon_map, caustics_map) from photon_build -> Scene::usePhotonMap = true."""
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     x0, y0, x1, y1 = region
     h, w = y1 - y0, x1 - x0
@@ -52,8 +89,16 @@ def render(blob, region, spp, max_bounce=5, seed=0x51A7A7, threads=0, spp_max=No
     cnt = Counters()
     spp_min = spp
     spp_max = spp if spp_max is None else spp_max
-    rc = lib().qa_oracle_render(blob.ctypes.data, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed,
-                                rgb.ctypes.data, depth.ctypes.data, ns.ctypes.data, threads, C.byref(cnt))
+    if photon is not None:
+        pp, pm, cm = photon
+        pm = np.ascontiguousarray(pm, PHOTON_DTYPE)
+        cm = np.ascontiguousarray(cm, PHOTON_DTYPE)
+        rc = lib().qa_oracle_render_pm(blob.ctypes.data, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed,
+                                       rgb.ctypes.data, depth.ctypes.data, ns.ctypes.data, threads, C.byref(cnt),
+                                       C.byref(pp), pm.ctypes.data, cm.ctypes.data)
+    else:
+        rc = lib().qa_oracle_render(blob.ctypes.data, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed,
+                                    rgb.ctypes.data, depth.ctypes.data, ns.ctypes.data, threads, C.byref(cnt))
     if rc != 0:
         raise RuntimeError(f"qa_oracle_render failed: {rc}")
     return rgb, depth, ns, cnt

@@ -13,6 +13,7 @@
 #include "qa_oracle.h"
 #include "qa_flat_scene.h"
 #include "qa_seed.h"
+#include "qa_photon.h"
 
 #include <math.h>
 #include <string.h>
@@ -91,6 +92,9 @@ typedef struct {
   const qa_texmap *texmap;
   const qa_texture *tex;
   int max_bounce;
+  /* Scene::usePhotonMap, photonmap, causticsmap (src/scene/scene.h:48-67); [0] photon, [1] caustics */
+  int use_pm;
+  struct { const qa_photon *photons; uint32_t count; int half; float radius; } pm[2];
 } scene_t;
 
 typedef struct {
@@ -784,7 +788,245 @@ static v3 secondary(const scene_t *s, const qa_material *m, v3 pos, v3 dir, v3 B
   return vdivs(vmul(incoming, BxDF), PDF);
 }
 
-/* MtlBlinn_PhotonMap::Shade, src/materials/MtlBlinn_PhotonMap.cpp:256-500 (usePhotonMap == false) */
+/* ------------------------------------------------------------------------------------------ */
+/* Photon maps (cy::PhotonMap, src/ext/cyPhotonMap.h)                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* Photon::SetPower, cyPhotonMap.h:214-220 (Color24(255.f * c / power): float -> uchar truncation) */
+static void photon_set_power(qa_photon *ph, v3 c)
+{
+  float power = c.x;
+  if (power < c.y) power = c.y;
+  if (power < c.z) power = c.z;
+  ph->power = power;
+  const v3 q = vdivs(vscale(c, 255.f), power);
+  ph->rgb[0] = (uint8_t) (int) q.x;
+  ph->rgb[1] = (uint8_t) (int) q.y;
+  ph->rgb[2] = (uint8_t) (int) q.z;
+}
+/* Photon::SetDirection, cyPhotonMap.h:222-231 */
+static void photon_set_direction(qa_photon *ph, v3 dir)
+{
+  ph->dirx = (int16_t) (dir.x * 0x7FFF);
+  ph->diry = (int16_t) (dir.y * 0x7FFF);
+  if (dir.z > 0) ph->plane_dirz &= 0x7;
+  else ph->plane_dirz = (uint8_t) (0x8 | (ph->plane_dirz & 0x7));
+}
+/* Photon::GetDirection, cyPhotonMap.h:233-254: z from x only ("dirX*dirX + dirY - dirY"), by a
+ * digit-by-digit integer square root */
+static v3 photon_get_direction(const qa_photon *ph)
+{
+  v3 dir;
+  dir.x = (float) ph->dirx / (float) 0x7FFF;
+  dir.y = (float) ph->diry / (float) 0x7FFF;
+  int xy2 = ph->dirx * ph->dirx + ph->diry - ph->diry;
+  if (xy2 > 0x3FFF0001) xy2 = 0x3FFF0001;
+  const int z2 = 0x3FFF0001 - xy2;
+  int root = 0, bit = 0x40000000, rem = z2;
+  while (bit > rem) bit >>= 2;
+  while (bit) {
+    if (rem >= root + bit) {
+      rem = rem - root - bit;
+      root = root + (bit << 1);
+    }
+    root >>= 1;
+    bit >>= 2;
+  }
+  dir.z = (float) root / (float) 0x7FFF;
+  if (ph->plane_dirz & 0x8) dir.z = -dir.z;
+  return dir;
+}
+static inline float axis_of(const float *p, int axis) { return p[axis]; }
+
+/* PhotonMap::BalanceSegment, cyPhotonMap.h:295-372: left-balanced kd-tree in heap order; the
+ * median is found with the reference's own quick-select (its swaps decide how ties are split) */
+static void balance_segment(qa_photon *photons, qa_photon *balanced, v3 boxMin, v3 boxMax, uint32_t index,
+                            uint32_t start, uint32_t end)
+{
+  uint32_t median = 1;
+  while ((4 * median) <= (end - start + 1)) median += median;
+  if ((3 * median) <= (end - start + 1)) {
+    median += median;
+    median += start - 1;
+  } else {
+    median = end - median + 1;
+  }
+  int axis = 2;
+  const v3 d = vsub(boxMax, boxMin);
+  if (d.x > d.y) {
+    if (d.x > d.z) axis = 0;
+  } else if (d.y > d.z) axis = 1;
+
+  uint32_t left = start, right = end;
+  while (right > left) {
+    const float v = photons[right].pos[axis];
+    uint32_t i = left - 1, j = right;
+    while (photons[++i].pos[axis] < v) {}
+    while (photons[--j].pos[axis] > v && j > left) {}
+    while (i < j) {
+      qa_photon t = photons[i]; photons[i] = photons[j]; photons[j] = t;
+      while (photons[++i].pos[axis] < v) {}
+      while (photons[--j].pos[axis] > v && j > left) {}
+    }
+    { qa_photon t = photons[i]; photons[i] = photons[right]; photons[right] = t; }
+    if (i >= median) right = i - 1;
+    if (i <= median) left = i + 1;
+  }
+  balanced[index] = photons[median];
+  balanced[index].plane_dirz = (uint8_t) ((balanced[index].plane_dirz & 0x8) | (axis & 0x3));
+  if (median > start) {
+    if (start < median - 1) {
+      v3 tmax = boxMax;
+      ((float *) &tmax)[axis] = balanced[index].pos[axis];
+      balance_segment(photons, balanced, boxMin, tmax, 2 * index, start, median - 1);
+    } else {
+      balanced[2 * index] = photons[start];
+    }
+  }
+  if (median < end) {
+    if (median + 1 < end) {
+      v3 tmin = boxMin;
+      ((float *) &tmin)[axis] = balanced[index].pos[axis];
+      balance_segment(photons, balanced, tmin, boxMax, 2 * index + 1, median + 1, end);
+    } else {
+      balanced[2 * index + 1] = photons[end];
+    }
+  }
+}
+
+/* PhotonMap::PrepareForIrradianceEstimation, cyPhotonMap.h:272-292.  photons: count+1 records,
+ * [0] is the value-initialised dummy the reference keeps (all zero: it takes part in the box). */
+static int balance(qa_photon *photons, uint32_t count)
+{
+  v3 bmin = v3p(photons[0].pos), bmax = bmin;
+  for (uint32_t i = 1; i <= count; ++i) {
+    const float *q = photons[i].pos;
+    if (bmin.x > q[0]) bmin.x = q[0];
+    if (bmax.x < q[0]) bmax.x = q[0];
+    if (bmin.y > q[1]) bmin.y = q[1];
+    if (bmax.y < q[1]) bmax.y = q[1];
+    if (bmin.z > q[2]) bmin.z = q[2];
+    if (bmax.z < q[2]) bmax.z = q[2];
+  }
+  qa_photon *balanced = (qa_photon *) calloc((size_t) count + 1, sizeof(qa_photon));
+  if (!balanced) return -1;
+  balance_segment(photons, balanced, bmin, bmax, 1, 1, count);
+  memcpy(photons, balanced, ((size_t) count + 1) * sizeof(qa_photon));
+  free(balanced);
+  return 0;
+}
+
+typedef struct {   /* PhotonMap::NearestPhotons, cyPhotonMap.h:189-198 (photon copies -> indices) */
+  v3 pos, normal;
+  int found;
+  float dist2[QA_PHOTON_GATHER + 1];
+  uint32_t photon[QA_PHOTON_GATHER + 1];
+} nearest_t;
+
+/* PhotonMap::LocatePhotons, cyPhotonMap.h:437-501 (normal given, ellipticity 1 => normScale 0) */
+static void locate_photons(const qa_photon *photons, int half, nearest_t *np, int index)
+{
+  const qa_photon *p = &photons[index];
+  const int axis = p->plane_dirz & 0x3;
+  if (index < half) {
+    const float dist = ((const float *) &np->pos)[axis] - p->pos[axis];
+    if (dist > 0) {
+      locate_photons(photons, half, np, 2 * index + 1);
+      if (dist * dist < np->dist2[0]) locate_photons(photons, half, np, 2 * index);
+    } else {
+      locate_photons(photons, half, np, 2 * index);
+      if (dist * dist < np->dist2[0]) locate_photons(photons, half, np, 2 * index + 1);
+    }
+  }
+  const v3 dif = vsub(v3p(p->pos), np->pos);
+  const float dist2 = vdot(dif, dif);
+  if (dist2 < np->dist2[0]) {
+    const v3 dir = photon_get_direction(p);
+    if (vdot(dir, np->normal) >= 0) return;
+    if (np->found < QA_PHOTON_GATHER) {
+      np->found++;
+      np->dist2[np->found] = dist2;
+      np->photon[np->found] = (uint32_t) index;
+      if (np->found == QA_PHOTON_GATHER) {  /* build the max-heap */
+        const int half_found = np->found >> 1;
+        for (int k = half_found; k >= 1; k--) {
+          int parent = k;
+          const uint32_t tp = np->photon[k];
+          const float td2 = np->dist2[k];
+          while (parent <= half_found) {
+            int j = parent + parent;
+            if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+            if (td2 >= np->dist2[j]) break;
+            np->dist2[parent] = np->dist2[j];
+            np->photon[parent] = np->photon[j];
+            parent = j;
+          }
+          np->photon[parent] = tp;
+          np->dist2[parent] = td2;
+        }
+      }
+    } else {
+      int parent = 1, j = 2;
+      while (j <= np->found) {
+        if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+        if (dist2 > np->dist2[j]) break;
+        np->dist2[parent] = np->dist2[j];
+        np->photon[parent] = np->photon[j];
+        parent = j;
+        j <<= 1;
+      }
+      np->photon[parent] = (uint32_t) index;
+      np->dist2[parent] = dist2;
+      np->dist2[0] = np->dist2[1];
+    }
+  }
+}
+
+/* PhotonMap::EstimateIrradiance<100>(..., &N, 1.f, FILTER_TYPE_QUADRATIC), cyPhotonMap.h:375-433 */
+static void estimate_irradiance(const scene_t *s, int which, v3 pos, v3 N, v3 *irrad, v3 *direction)
+{
+  *irrad = V3(0, 0, 0);
+  *direction = V3(0, 0, 0);
+  const qa_photon *photons = s->pm[which].photons;
+  nearest_t np;
+  np.pos = pos;
+  np.normal = N;
+  np.found = 0;
+  np.dist2[0] = s->pm[which].radius * s->pm[which].radius;
+  locate_photons(photons, s->pm[which].half, &np, 1);
+  for (int i = 1; i <= np.found; i++) {
+    const qa_photon *ph = &photons[np.photon[i]];
+    const v3 power = vscale(V3(ph->rgb[0] / 255.0f, ph->rgb[1] / 255.0f, ph->rgb[2] / 255.0f), ph->power);
+    const float filter = 1 - np.dist2[i] / np.dist2[0];
+    *irrad = vadd(*irrad, vscale(power, filter));
+    const v3 dir = photon_get_direction(ph);
+    *direction = vadd(*direction, vscale(dir, filter * ph->power));
+  }
+  if (np.found > 0) {
+    const float area = ((float) M_PI * 0.5f) * np.dist2[0];
+    if (area > 0) {
+      const float one_over_area = 1.0f / area;
+      *irrad = vscale(*irrad, one_over_area);
+    }
+    *direction = vnormalize(*direction);
+  }
+}
+
+/* the gather term of Shade, MtlBlinn_PhotonMap.cpp:426-458 */
+static v3 gather(const scene_t *s, int which, v3 p, v3 N, v3 V, v3 kd, v3 ks, float gloss)
+{
+  v3 I, D;
+  estimate_irradiance(s, which, p, N, &I, &D);
+  if (luma(I) > 0.00001f) {
+    const v3 L = vneg(vnormalize(D));
+    const v3 H = vnormalize(vadd(V, L));
+    const float cosNL = QMAX(0.f, vdot(N, L));
+    const float cosNH = QMAX(0.f, vdot(N, H));
+    return vmul(vscale(I, cosNL), vadd(kd, vscale(ks, powf(cosNH, gloss))));
+  }
+  return V3(0, 0, 0);
+}
+
+/* MtlBlinn_PhotonMap::Shade, src/materials/MtlBlinn_PhotonMap.cpp:256-500 */
 static v3 shade_blinn(const scene_t *s, const qa_material *m, const diffray_t *ray, const diffhit_t *h,
                       int bounce, tls_t *tl)
 {
@@ -835,9 +1077,13 @@ static v3 shade_blinn(const scene_t *s, const qa_material *m, const diffray_t *r
   }
   const int doReflect = select == REFLECT;
   const int doTransmit = select == TRANSMIT;
-  int doDiffuse = 0;
+  int doDiffuse = 0, doGatherPhoton = 0, doGatherCaustics = 0;
   if (select == DIFFUSE) {
     if (!h->c.hasDiffuseHit) doDiffuse = 1;
+    if (s->use_pm) {                     /* :349-359 */
+      doGatherPhoton = h->c.hasDiffuseHit;
+      doGatherCaustics = 1;
+    }
   }
   if (bounce > 0) {
     if (luma(sampleReflection) > 0.00001f) {
@@ -866,6 +1112,8 @@ static v3 shade_blinn(const scene_t *s, const qa_material *m, const diffray_t *r
     }
   }
   if (luma(sampleDiffuse) > 0.00001f) {
+    if (doGatherPhoton) color = vadd(color, gather(s, 0, p, N, V, sampleDiffuse, sampleSpecular, m->gloss_spec));
+    if (doGatherCaustics) color = vadd(color, gather(s, 1, p, N, V, sampleDiffuse, sampleSpecular, m->gloss_spec));
     if (bounce > 0) {
       if (doDiffuse) {
         if (h->c.hasFrontHit) {
@@ -910,6 +1158,234 @@ static v3 shade(const scene_t *s, const diffray_t *ray, const diffhit_t *h, int 
     return V3(1, 1, 1);
   }
   return shade_blinn(s, &s->mtl[ms->first], ray, h, bounce, tl);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Photon tracing                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+static int scene_bind(scene_t *s, const void *blob);
+
+/* Sampler::UniformSphere / UniformHemisphere, src/core/sampler.cpp:55-85 */
+static v3 uniform_sphere(tls_t *t)
+{
+  float r1 = rng1(t), r2 = rng1(t);
+  r1 = r1 * 2.f - 1.f;
+  const float cosTheta = r1;
+  const float sinTheta = sqrtf(1 - r1 * r1);
+  const float phi = 2 * kPI * r2;
+  return V3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+}
+static v3 uniform_hemisphere(tls_t *t)
+{
+  float r1 = rng1(t), r2 = rng1(t);
+  const float cosTheta = r1;
+  const float sinTheta = sqrtf(1 - r1 * r1);
+  const float phi = 2 * kPI * r2;
+  return V3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+}
+
+/* Material of a hit for the photon extensions: 0 = none, 1 = MtlBlinn (*out), 2 = MultiMtl, which
+ * inherits Material::IsPhotonSurface (true) and RandomPhotonBounce (false), src/core/material.h:53-63 */
+static int photon_material(const scene_t *s, const diffhit_t *h, const qa_material **out)
+{
+  const qa_instance *in = &s->inst[h->c.node];
+  if (in->mtlset < 0) return 0;
+  const qa_mtlset *ms = &s->mtlset[in->mtlset];
+  if (ms->multi) return 2;
+  *out = &s->mtl[ms->first];
+  return 1;
+}
+
+/* MtlBlinn_PhotonMap::RandomPhotonBounce, src/materials/MtlBlinn_PhotonMap.cpp:503-578 */
+static int photon_bounce(const scene_t *s, const qa_material *m, diffray_t *ray, v3 *c, const diffhit_t *h, tls_t *tl)
+{
+  (void) mtl_sample(s, h, &m->emission);
+  const v3 V = vneg(ray->c.dir);
+  const v3 N = h->c.N;
+  const v3 Y = vdot(N, V) > 0.f ? N : vneg(N);
+  v3 tDir, rDir;
+  float tC, rC;
+  int totReflection;
+  {
+    const v3 Z = vcross(V, Y);
+    const v3 X = vnormalize(vcross(Y, Z));
+    const float nIOR = h->c.hasFrontHit ? 1.f / m->ior : m->ior;
+    const float cosI = vdot(N, V);
+    const float sinI = sqrtf(1 - cosI * cosI);
+    const float sinO = QMAX(0.f, QMIN(1.f, sinI * nIOR));
+    const float cosO = sqrtf(1.f - sinO * sinO);
+    tDir = vsub(vscale(vneg(X), sinO), vscale(Y, cosO));
+    rDir = vsub(vscale(vscale(N, 2.f), vdot(N, V)), V);
+    totReflection = (nIOR * sinI) > 1.001f;
+    const float C = (nIOR - 1.f) * (nIOR - 1.f) / ((nIOR + 1.f) * (nIOR + 1.f));
+    rC = C + (1.f - C) * powf(1.f - QABS(cosI), 5.f);
+    tC = 1.f - rC;
+  }
+  const v3 tK = mtl_sample(s, h, &m->refraction);
+  const v3 rK = mtl_sample(s, h, &m->reflection);
+  const v3 sampleTransmission = totReflection ? V3(0, 0, 0) : vscale(tK, tC);
+  const v3 sampleReflection = totReflection ? vadd(rK, tK) : vadd(rK, vscale(tK, rC));
+  const v3 sampleDiffuse = mtl_sample(s, h, &m->diffuse);
+  const v3 sampleSpecular = mtl_sample(s, h, &m->specular);
+  /* RandomSelectMtl with its scale output, :107-150 */
+  const float lumaT = luma(sampleTransmission), lumaR = luma(sampleReflection), lumaD = luma(sampleDiffuse);
+  const float r = rng1(tl);
+  const float coefTransmit = lumaT;
+  const float coefReflection = coefTransmit + lumaR;
+  const float coefDiffuse = coefReflection + lumaD;
+  const float coefAbsorb = coefDiffuse + m->kill;
+  const float rcpCoefSum = 1.f / coefAbsorb;
+  const float sel = r * coefAbsorb;
+  v3 sampleDir = V3(0, 0, 0), BxDF = V3(0, 0, 0);
+  float PDF = 1.f, scale;
+  int doShade = 0;
+  if (sel < coefTransmit && lumaT > 0.00001f) {
+    scale = lumaT * rcpCoefSum;
+    if (m->gloss_refr > 0.f) {
+      do {
+        sampleDir = vnormalize(vadd(vnormalize(tDir), uniform_ball(tl, 2.f * m->gloss_refr)));
+      } while (vdot(sampleDir, Y) > 0);
+    } else sampleDir = tDir;
+    BxDF = sampleTransmission;
+    doShade = 1;
+  } else if (sel < coefReflection && lumaR > 0.00001f) {
+    scale = lumaR * rcpCoefSum;
+    if (m->gloss_refl > 0.f) {
+      do {
+        sampleDir = vnormalize(vadd(vnormalize(rDir), uniform_ball(tl, 2.f * m->gloss_refl)));
+      } while (vdot(sampleDir, Y) < 0);
+    } else sampleDir = rDir;
+    BxDF = sampleReflection;
+    doShade = 1;
+  } else if (sel < coefDiffuse && lumaD > 0.00001f) {
+    scale = lumaD * rcpCoefSum;
+    if (h->c.hasFrontHit) {
+      /* SampleDiffuseBxDF(..., photonMap = true), :203-224 */
+      sampleDir = to_local_frame(N, uniform_hemisphere(tl));
+      const v3 L = vnormalize(sampleDir);
+      const v3 H = vnormalize(vadd(V, L));
+      const float cosNH = QMAX(0.f, vdot(N, H));
+      BxDF = vadd(sampleDiffuse, vscale(sampleSpecular, powf(cosNH, m->gloss_spec)));
+      PDF = 0.5f;
+      doShade = 1;
+    }
+  } else {
+    scale = coefAbsorb * rcpCoefSum;
+  }
+  if (!doShade) return 0;
+  /* DiffRay(p, dir).Normalize() here and ray.Normalize() once more in the emission loop (renderer.cpp:183,253) */
+  ray->c.p = h->c.p; ray->c.dir = vnormalize(vnormalize(sampleDir));
+  ray->x = ray->c; ray->y = ray->c;
+  ray->hasDiffRay = 0;
+  *c = vdivs(vmul(*c, BxDF), PDF * scale);
+  if (!h->c.hasFrontHit) *c = vmul(*c, attenuation(m->absorption, h->c.z));
+  return 1;
+}
+
+/* One iteration of the emission loops of Renderer::ComputeScene (src/renderers/renderer.cpp:146-197
+ * photon map, :217-271 caustics map) on the emission's own stream (include/qa_photon.h).
+ * Writes the photons this emission would store, in order, to out[0..]; returns their number
+ * (at most bounce - 1). */
+static int emit_photon(const scene_t *s, int caustics, uint32_t max_bounce, const int *photonLights, int numPhotonLights,
+                       uint32_t seed, uint32_t emission, qa_photon *out, tls_t *tl)
+{
+  tl->rng = qa_photon_seed(seed, caustics ? QA_STREAM_CAUSTICS : QA_STREAM_PHOTON, emission);
+  const float lightScale = 1.f / (float) numPhotonLights;
+  const qa_light *light;
+  if (numPhotonLights == 1) light = &s->light[photonLights[0]];
+  else {
+    const float r = rng1(tl);
+    size_t id;
+    if (!caustics) {
+      const float fl = floorf(r * (float) (size_t) numPhotonLights);
+      const float lim = (float) (size_t) (numPhotonLights - 1);
+      id = (size_t) (fl < lim ? fl : lim);
+    } else {
+      const size_t ce = (size_t) ceilf(r * (float) (size_t) numPhotonLights);
+      id = ce < (size_t) (numPhotonLights - 1) ? ce : (size_t) (numPhotonLights - 1);
+    }
+    light = &s->light[photonLights[id]];
+  }
+  /* PointLight::RandomPhoton, src/lights/lights.cpp:76-80 */
+  diffray_t ray;
+  ray.c.p = v3p(light->position);
+  ray.c.dir = vnormalize(uniform_sphere(tl));
+  ray.x = ray.c; ray.y = ray.c;
+  ray.hasDiffRay = 0;
+  diffhit_t h;
+  hit_init(&h);
+  v3 intensity = vscale(v3p(light->intensity), lightScale);
+  int stored = 0;
+  uint32_t bounce = 0;
+  while (bounce < max_bounce) {
+    if (!trace_normal(s, &ray, &h, tl)) break;
+    const qa_material *m = NULL;
+    const int kind = photon_material(s, &h, &m);
+    if (kind == 0) break;  /* the reference dereferences a null Material here */
+    const int photonSurface = kind == 2 ? 1 : (luma(v3p(m->diffuse.color)) > 0);
+    if (photonSurface && bounce != 0 && !(caustics && h.c.hasDiffuseHit)) {
+      qa_photon *ph = &out[stored++];
+      memset(ph, 0, sizeof(*ph));
+      ph->pos[0] = h.c.p.x; ph->pos[1] = h.c.p.y; ph->pos[2] = h.c.p.z;
+      photon_set_direction(ph, ray.c.dir);
+      photon_set_power(ph, intensity);
+    }
+    if (kind != 1 || !photon_bounce(s, m, &ray, &intensity, &h, tl)) break;
+    const int diffuseHit = h.c.hasDiffuseHit;
+    ++bounce;
+    hit_init(&h);
+    if (caustics) h.c.hasDiffuseHit = (diffuseHit || photonSurface);
+  }
+  return stored;
+}
+
+/* Both maps of Renderer::ComputeScene.  photon / caustics: size + 1 records each ([0] = dummy).
+ * emitted[2]: numOfEmittedRays of each map; emissions[2]: loop iterations until the map was full.
+ * Returns 0; -3 when the scene has no photon source (the reference divides by zero and reads an
+ * uninitialised light there); -4 when a map is not full after QA_PHOTON_MAX_EMISSIONS emissions (the
+ * reference loops forever). */
+int qa_oracle_photon_build(const void *blob, const qa_photon_params *pp, uint32_t seed, qa_photon *photon,
+                           qa_photon *caustics, uint64_t emitted[2], uint64_t emissions[2])
+{
+  scene_t s;
+  if (scene_bind(&s, blob) != 0) return -1;
+  memset(s.pm, 0, sizeof(s.pm));
+  s.use_pm = 0;
+  s.max_bounce = 0;
+  int lights[256], nl = 0;
+  for (uint32_t i = 0; i < s.h->num_lights && nl < 256; ++i)
+    if (s.light[i].type == QA_LIGHT_POINT) lights[nl++] = (int) i;   /* IsPhotonSource, lights.h:114,156 */
+  if (nl == 0) return -3;
+  tls_t tl;
+  memset(&tl, 0, sizeof(tl));
+  for (int which = 0; which < 2; ++which) {
+    const qa_photon_map_params *mp = which ? &pp->caustics : &pp->photon;
+    qa_photon *map = which ? caustics : photon;
+    memset(map, 0, ((size_t) mp->size + 1) * sizeof(qa_photon));
+    qa_photon *tmp = (qa_photon *) malloc(((size_t) mp->bounce + 1) * sizeof(qa_photon));
+    uint64_t recorded = 0, numEmitted = 0, e = 0;
+    int finished = 0;
+    while (!finished) {
+      if (e >= QA_PHOTON_MAX_EMISSIONS(mp->size)) { free(tmp); return -4; }
+      const int n = emit_photon(&s, which, mp->bounce, lights, nl, seed, (uint32_t) e, tmp, &tl);
+      int any = 0;
+      for (int k = 0; k < n; ++k) {
+        if (recorded >= mp->size) { finished = 1; break; }
+        map[1 + recorded++] = tmp[k];
+        any = 1;
+      }
+      if (any) ++numEmitted;
+      ++e;
+    }
+    free(tmp);
+    /* ScalePhotonPowers(1.f / numOfEmittedRays), cyPhotonMap.h:128-132 */
+    const float scale = 1.f / (float) (uint32_t) numEmitted;
+    for (uint32_t i = 1; i <= mp->size; ++i) map[i].power *= scale;
+    if (balance(map, mp->size) != 0) return -5;
+    emitted[which] = numEmitted;
+    emissions[which] = e;
+  }
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -996,8 +1472,26 @@ int qa_oracle_render(const void *blob, int x0, int y0, int x1, int y1, int spp_m
                      int max_bounce, uint32_t seed, float *rgb, float *depth, uint32_t *ns,
                      int threads, qa_oracle_counters *counters)
 {
+  return qa_oracle_render_pm(blob, x0, y0, x1, y1, spp_min, spp_max, max_bounce, seed, rgb, depth, ns, threads,
+                             counters, NULL, NULL, NULL);
+}
+
+int qa_oracle_render_pm(const void *blob, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
+                        int max_bounce, uint32_t seed, float *rgb, float *depth, uint32_t *ns,
+                        int threads, qa_oracle_counters *counters, const qa_photon_params *pp,
+                        const qa_photon *photon, const qa_photon *caustics)
+{
   scene_t s;
   if (scene_bind(&s, blob) != 0) return -1;
+  memset(s.pm, 0, sizeof(s.pm));
+  s.use_pm = pp != NULL;
+  if (pp) {
+    /* halfStoredPhotons = (photons.size() - 1) / 2 - 1, cyPhotonMap.h:291 */
+    s.pm[0].photons = photon;   s.pm[0].count = pp->photon.size;   s.pm[0].radius = pp->photon.radius;
+    s.pm[0].half = (int) (pp->photon.size / 2) - 1;
+    s.pm[1].photons = caustics; s.pm[1].count = pp->caustics.size; s.pm[1].radius = pp->caustics.radius;
+    s.pm[1].half = (int) (pp->caustics.size / 2) - 1;
+  }
   if (x0 < 0 || y0 < 0 || x1 > (int) s.h->width || y1 > (int) s.h->height || x1 < x0 || y1 < y0) return -2;
   s.max_bounce = max_bounce;
   const int cw = x1 - x0, ch = y1 - y0;

@@ -15,6 +15,8 @@
 
 #include <stdint.h>
 
+#include "qa_photon.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -33,6 +35,19 @@ typedef struct qa_oracle_counters {
 int qa_oracle_render(const void *blob, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
                      int max_bounce, uint32_t seed, float *rgb, float *depth, uint32_t *ns,
                      int threads, qa_oracle_counters *counters);
+
+/* Photon / caustics maps of Renderer::ComputeScene (-use-photon-map), one RNG stream per emission
+ * (include/qa_photon.h).  photon / caustics: pp->*.size + 1 records, [0] unused, [1..size] the
+ * balanced kd-tree in heap order (byte-compatible with the reference's photonmap.dat / caustics.dat
+ * dumps).  emitted: numOfEmittedRays per map; emissions: loop iterations per map. */
+int qa_oracle_photon_build(const void *blob, const qa_photon_params *pp, uint32_t seed, qa_photon *photon,
+                           qa_photon *caustics, uint64_t emitted[2], uint64_t emissions[2]);
+
+/* qa_oracle_render with Scene::usePhotonMap = true when pp != NULL (maps from qa_oracle_photon_build). */
+int qa_oracle_render_pm(const void *blob, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
+                        int max_bounce, uint32_t seed, float *rgb, float *depth, uint32_t *ns,
+                        int threads, qa_oracle_counters *counters, const qa_photon_params *pp,
+                        const qa_photon *photon, const qa_photon *caustics);
 
 /* Small pieces exposed for unit tests. */
 float qa_oracle_halton(int index, int base);

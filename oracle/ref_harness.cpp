@@ -14,6 +14,11 @@
 //      TexturedColor::Sample) following src/renderers/renderer.cpp:302-346, but keeps the
 //      LINEAR FLOAT mean radiance, the first-sample depth and the sample count;
 //   3. counts top-level ray casts with linker --wrap on Scene::TraceNodeNormal/Shadow;
+//   5. with --photon-map, fills Scene::photonmap / causticsmap through the reference's own
+//      Light::RandomPhoton, Scene::TraceNodeNormal, Material::RandomPhotonBounce and cyPhotonMap
+//      (store, scale, balance), one emission at a time as src/renderers/renderer.cpp:146-271
+//      does, but on one RNG stream per emission (include/qa_photon.h), sets Scene::usePhotonMap
+//      and dumps the balanced arrays (<out>.photonmap.bin, <out>.caustics.bin);
 //   4. can dump what the reference's loader built (node tree, mesh faces, BVH) as JSON so the
 //      repo's own loader / BVH builder / flattener can be compared field by field.
 // All tracing and shading arithmetic is executed by the reference's code.
@@ -42,13 +47,15 @@
 #include "parser/xmlload.h"
 
 #include "qa_seed.h"
+#include "qa_photon.h"
 
 // ---------------------------------------------------------------------------------------------
 // rand()/srand() interposition (the executable's definitions win over libc's)
 // ---------------------------------------------------------------------------------------------
 static uint32_t g_seed = QA_DEFAULT_SEED;
 static thread_local uint32_t tl_pixel = 0;
-extern "C" int rand(void) { return (int) qa_pixel_rand(g_seed, tl_pixel); }
+static thread_local uint32_t tl_stream = 0;   // 0: pixel streams; QA_STREAM_PHOTON / QA_STREAM_CAUSTICS: emissions
+extern "C" int rand(void) { return (int) qa_pixel_rand(g_seed ^ tl_stream, tl_pixel); }
 extern "C" void srand(unsigned) {}
 
 // ---------------------------------------------------------------------------------------------
@@ -87,6 +94,8 @@ struct Options {
   int sppMin = 1, sppMax = 1;
   int bounce = 5;
   int threads = 1;
+  bool photonMap = false;
+  qa_photon_params pm = {{10000, 20, 0.2f}, {1000, 20, 1.0f}};   // RendererParam defaults, renderer.h:51-57
   const char *dumpScene = nullptr;
   bool render = true;
 };
@@ -96,9 +105,78 @@ class HarnessRenderer : public qaray::Renderer {
   explicit HarnessRenderer(RendererParam &p) : qaray::Renderer(p) {}
   void Render() override {}
 
+  // Fill one of the two maps.  The bookkeeping (which hits are stored, when the map is full, what
+  // counts as an emitted ray) is that of renderer.cpp:146-197 / :217-271; everything numeric is a
+  // call into the reference.
+  void FillMap(qaray::PhotonMap &pm, bool caustics, const qa_photon_map_params &mp, uint64_t &emitted, uint64_t &emissions)
+  {
+    std::vector<Light *> sources;
+    for (auto l : scene->lights) if (l->IsPhotonSource()) sources.push_back(l);
+    if (sources.empty()) { fprintf(stderr, "photon map: the scene has no photon source\n"); exit(3); }
+    const qaFLOAT lightScale = 1.f / static_cast<qaFLOAT>(sources.size());
+    pm.size = mp.size; pm.radius = mp.radius; pm.bounce = mp.bounce;
+    pm.map.CreateAllPhotons(mp.size);
+    tl_stream = caustics ? QA_STREAM_CAUSTICS : QA_STREAM_PHOTON;
+    size_t stored = 0;
+    emitted = 0;
+    bool full = false;
+    uint32_t e = 0;
+    for (; !full; ++e) {
+      if (e >= QA_PHOTON_MAX_EMISSIONS(mp.size)) { fprintf(stderr, "photon map: not full after %u emissions\n", e); exit(4); }
+      tl_pixel = e;
+      qaray::rng->local() = qaray::Sampler_Marsaglia();
+      Light *light = sources[0];
+      if (sources.size() > 1) {
+        qaFLOAT r;
+        qaray::rng->local().Get1f(r);
+        size_t id = caustics ? MIN(static_cast<size_t>(CEIL(r * sources.size())), sources.size() - 1)
+                             : MIN(FLOOR(r * sources.size()), sources.size() - 1);
+        light = sources[id];
+      }
+      DiffRay ray = light->RandomPhoton();
+      ray.Normalize();
+      DiffHitInfo hit;
+      hit.Init();
+      Color3f power = light->GetPhotonIntensity(ray.c.dir) * lightScale;
+      bool any = false;
+      for (size_t bounce = 0; bounce < mp.bounce;) {
+        if (!scene->TraceNodeNormal(scene->rootNode, ray, hit)) break;
+        const Material *mtl = hit.c.node->GetMaterial();
+        if (!mtl) break;
+        const bool surface = mtl->IsPhotonSurface(0);
+        if (surface && bounce != 0 && !(caustics && hit.c.hasDiffuseHit)) {
+          if (stored >= mp.size) { full = true; break; }
+          pm.map[stored].position = hit.c.p;
+          pm.map[stored].SetDirection(ray.c.dir);
+          pm.map[stored].SetPower(power);
+          ++stored;
+          any = true;
+        }
+        if (!mtl->RandomPhotonBounce(ray, power, hit)) break;
+        const bool wasDiffuse = hit.c.hasDiffuseHit;
+        ++bounce;
+        ray.Normalize();
+        hit.Init();
+        if (caustics) hit.c.hasDiffuseHit = (wasDiffuse || surface);
+      }
+      if (any) ++emitted;
+    }
+    emissions = e;
+    pm.map.ScalePhotonPowers(1.f / static_cast<qaUINT>(emitted));
+    pm.map.PrepareForIrradianceEstimation();
+    tl_stream = 0;
+  }
+  void BuildPhotonMaps(const qa_photon_params &pp, uint64_t emitted[2], uint64_t emissions[2])
+  {
+    FillMap(scene->photonmap, false, pp.photon, emitted[0], emissions[0]);
+    FillMap(scene->causticsmap, true, pp.caustics, emitted[1], emissions[1]);
+    scene->usePhotonMap = true;
+  }
+
   // One pixel: the sample loop of renderer.cpp:302-346 with float outputs.
   void Pixel(int i, int j, float *rgb, float *depthOut, uint32_t *nsOut)
   {
+    tl_stream = 0;
     tl_pixel = (uint32_t) j * (uint32_t) pixelW + (uint32_t) i;
     qaray::rng->local() = qaray::Sampler_Marsaglia();  // fresh, un-initialised stream
     SuperSamplerHalton pix(Color3f(0.005f, 0.001f, 0.005f), (int) param.sppMin, (int) param.sppMax);
@@ -249,6 +327,7 @@ static void Usage()
   fprintf(stderr,
           "usage: ref_harness scene.xml [--size W H] [--crop x0 y0 x1 y1] [--spp N | --spp-min A --spp-max B]\n"
           "                   [--bounce B] [--seed S] [--threads T] [--out prefix] [--dump-scene file.json] [--no-render]\n"
+          "                   [--photon-map N_PHOTON N_CAUSTICS] [--photon-bounce B B] [--photon-radius R R]\n"
           "       (run with the scene's asset root as the working directory)\n");
 }
 
@@ -267,6 +346,9 @@ int main(int argc, char **argv)
     else if (s == "--seed") { need(1); g_seed = (uint32_t) strtoul(argv[++a], nullptr, 0); }
     else if (s == "--threads") { need(1); o.threads = atoi(argv[++a]); }
     else if (s == "--out") { need(1); o.out = argv[++a]; }
+    else if (s == "--photon-map") { need(2); o.photonMap = true; o.pm.photon.size = (uint32_t) atoi(argv[++a]); o.pm.caustics.size = (uint32_t) atoi(argv[++a]); }
+    else if (s == "--photon-bounce") { need(2); o.pm.photon.bounce = (uint32_t) atoi(argv[++a]); o.pm.caustics.bounce = (uint32_t) atoi(argv[++a]); }
+    else if (s == "--photon-radius") { need(2); o.pm.photon.radius = (float) atof(argv[++a]); o.pm.caustics.radius = (float) atof(argv[++a]); }
     else if (s == "--dump-scene") { need(1); o.dumpScene = argv[++a]; }
     else if (s == "--no-render") { o.render = false; }
     else if (s[0] == '-') { Usage(); return 2; }
@@ -291,6 +373,22 @@ int main(int argc, char **argv)
     fprintf(stderr, "bad crop\n"); return 2;
   }
   if (o.dumpScene) DumpScene(o.dumpScene, R);
+  uint64_t pmEmitted[2] = {0, 0}, pmEmissions[2] = {0, 0};
+  if (o.photonMap) {
+    static_assert(sizeof(qa_photon) == sizeof(cyPhotonMap::Photon), "qa_photon must mirror cy::PhotonMap::Photon");
+    R.BuildPhotonMaps(o.pm, pmEmitted, pmEmissions);
+    const struct { const char *ext; qaray::PhotonMap *m; } maps[2] = {{".photonmap.bin", &qaray::scene.photonmap},
+                                                                    {".caustics.bin", &qaray::scene.causticsmap}};
+    for (auto &mm : maps) {
+      FILE *pf = fopen((o.out + mm.ext).c_str(), "wb");
+      if (!pf) { perror(mm.ext); return 2; }
+      fwrite(mm.m->map.GetPhotons(), sizeof(cyPhotonMap::Photon), mm.m->map.NumPhotons(), pf);
+      fclose(pf);
+    }
+    printf("ref_harness: photon map %u photons from %llu emitted rays (%llu emissions), caustics map %u from %llu (%llu)\n",
+           o.pm.photon.size, (unsigned long long) pmEmitted[0], (unsigned long long) pmEmissions[0], o.pm.caustics.size,
+           (unsigned long long) pmEmitted[1], (unsigned long long) pmEmissions[1]);
+  }
   if (!o.render) return 0;
 
   const size_t maxThreads = qaray::tasking::get_num_of_threads();
@@ -329,11 +427,13 @@ int main(int argc, char **argv)
           "{\"producer\":\"oracle/ref_harness (reference code, float outputs)\",\"scene\":\"%s\","
           "\"width\":%d,\"height\":%d,\"crop\":[%d,%d,%d,%d],\"spp_min\":%d,\"spp_max\":%d,"
           "\"bounce\":%d,\"seed\":%u,\"threads\":%d,\"seconds\":%.6f,\"samples\":%llu,"
-          "\"casts_normal\":%llu,\"casts_shadow\":%llu,\"msamples_per_s\":%.6f}\n",
+          "\"casts_normal\":%llu,\"casts_shadow\":%llu,\"msamples_per_s\":%.6f,"
+          "\"photon_map\":%d,\"photon_emitted\":[%llu,%llu],\"photon_emissions\":[%llu,%llu]}\n",
           o.sceneFile, W, H, o.crop[0], o.crop[1], o.crop[2], o.crop[3], o.sppMin, o.sppMax,
           o.bounce, g_seed, o.threads, sec, (unsigned long long) samples.load(),
           (unsigned long long) castsN.load(), (unsigned long long) castsS.load(),
-          samples.load() / sec * 1e-6);
+          samples.load() / sec * 1e-6, o.photonMap ? 1 : 0, (unsigned long long) pmEmitted[0],
+          (unsigned long long) pmEmitted[1], (unsigned long long) pmEmissions[0], (unsigned long long) pmEmissions[1]);
   fclose(f);
   printf("ref_harness: %dx%d crop %dx%d spp %d..%d threads %d: %.3f s, %.4f Msamples/s, casts/sample %.3f normal + %.3f shadow\n",
          W, H, cw, ch, o.sppMin, o.sppMax, o.threads, sec, samples.load() / sec * 1e-6,

@@ -33,6 +33,19 @@ def load_golden(name):
     return z["rgb"], z["depth"], z["ns"], meta
 
 
+def photon_golden_names():
+    d = os.path.join(GOLDEN, "photon")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".npz"))
+
+
+def load_photon_golden(name):
+    """-> dict with rgb, depth, ns, photon, caustics (balanced qa_photon arrays without the [0] slot), meta."""
+    z = np.load(os.path.join(GOLDEN, "photon", name + ".npz"))
+    out = {k: z[k] for k in ("rgb", "depth", "ns", "photon", "caustics")}
+    out["meta"] = json.loads(bytes(z["meta"]).decode())
+    return out
+
+
 def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
 

@@ -41,6 +41,16 @@ CASES = [
 ]
 SEED = 0x51A7A7
 
+# -use-photon-map cases (tests/golden/photon/): name, scene, (W,H), spp, (size, bounce, radius) of the photon map
+# and of the caustics map.  One RNG stream per emission, include/qa_photon.h.
+PHOTON_CASES = [
+    ("pm_glass_48x36_2spp", "trc_mtl_glass.xml", (48, 36), 2, (2000, 20, 2.0), (300, 20, 3.0)),
+    ("pm_custom_64x48_2spp", "custom_photon.xml", (64, 48), 2, (5000, 20, 0.2), (800, 20, 1.0)),   # default radii
+    ("pm_glossy_shortpaths_48x36_2spp", "trc_mtl_glossy.xml", (48, 36), 2, (1500, 4, 1.0), (200, 6, 2.0)),
+]
+PHOTON_DTYPE = np.dtype([("pos", np.float32, 3), ("power", np.float32), ("rgb", np.uint8, 3), ("plane_dirz", np.uint8),
+                         ("dirx", np.int16), ("diry", np.int16)])   # cy::PhotonMap::Photon, 24 bytes
+
 
 def main():
     subprocess.run([sys.executable, os.path.join(SCENES, "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
@@ -66,6 +76,27 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=rgb, depth=depth, ns=ns,
                             meta=np.frombuffer(json.dumps(info).encode(), dtype=np.uint8))
         print(f"{name}: {cw}x{ch} samples={meta['samples']} casts={meta['casts_normal']}+{meta['casts_shadow']}")
+    os.makedirs(os.path.join(HERE, "photon"), exist_ok=True)
+    for name, scene, (w, h), spp, pm, cm in PHOTON_CASES:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "g")
+            cmd = [HARNESS, scene, "--size", str(w), str(h), "--spp", str(spp), "--seed", str(SEED), "--threads", "8",
+                   "--out", out, "--photon-map", str(pm[0]), str(cm[0]), "--photon-bounce", str(pm[1]), str(cm[1]),
+                   "--photon-radius", repr(pm[2]), repr(cm[2])]
+            subprocess.run(cmd, cwd=SCENES, check=True, stdout=subprocess.DEVNULL)
+            meta = json.load(open(out + ".json"))
+            rgb = np.fromfile(out + ".rgb.f32", np.float32).reshape(h, w, 3)
+            depth = np.fromfile(out + ".depth.f32", np.float32).reshape(h, w)
+            ns = np.fromfile(out + ".ns.u32", np.uint32).reshape(h, w)
+            photon = np.fromfile(out + ".photonmap.bin", PHOTON_DTYPE)
+            caustics = np.fromfile(out + ".caustics.bin", PHOTON_DTYPE)
+        info = dict(scene=scene, width=w, height=h, crop=[0, 0, w, h], spp_min=spp, spp_max=spp, bounce=5, seed=SEED,
+                    samples=meta["samples"], casts_normal=meta["casts_normal"], casts_shadow=meta["casts_shadow"],
+                    photon=list(pm), caustics=list(cm), emitted=meta["photon_emitted"], emissions=meta["photon_emissions"],
+                    producer="oracle/_ref/ref_harness --photon-map (reference code, one RNG stream per emission)")
+        np.savez_compressed(os.path.join(HERE, "photon", name + ".npz"), rgb=rgb, depth=depth, ns=ns, photon=photon,
+                            caustics=caustics, meta=np.frombuffer(json.dumps(info).encode(), dtype=np.uint8))
+        print(f"{name}: photons {len(photon)}+{len(caustics)} emitted {meta['photon_emitted']} emissions {meta['photon_emissions']}")
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ This also pins the host loader/flattener, because the goldens start from the XML
 import numpy as np
 import pytest
 
-from conftest import bits, golden_blob, golden_names, load_golden
+from conftest import bits, golden_blob, golden_names, load_golden, load_photon_golden, photon_golden_names
 from oracle import binding as oracle
 
 
@@ -22,6 +22,39 @@ def test_oracle_matches_reference_bit_for_bit(name):
     assert cnt.samples == meta["samples"]
     assert cnt.casts_normal == meta["casts_normal"]
     assert cnt.casts_shadow == meta["casts_shadow"]
+
+
+@pytest.mark.parametrize("name", photon_golden_names())
+def test_oracle_photon_maps_match_reference_bit_for_bit(name):
+    """-use-photon-map: the stored photons (after the reference's scaling and kd-tree balancing), the
+    emitted-ray counts and the image gathered from the maps, against the reference's own
+    Light::RandomPhoton / RandomPhotonBounce / cyPhotonMap code (oracle/ref_harness.cpp FillMap)."""
+    g = load_photon_golden(name)
+    meta = g["meta"]
+    blob = golden_blob(meta)
+    pp = oracle.photon_params(tuple(meta["photon"]), tuple(meta["caustics"]))
+    pm, cm, emitted, emissions = oracle.photon_build(blob, pp, seed=meta["seed"])
+    assert emitted == meta["emitted"] and emissions == meta["emissions"]
+    assert pm[1:].tobytes() == g["photon"].tobytes()
+    assert cm[1:].tobytes() == g["caustics"].tobytes()
+    rgb, depth, ns, cnt = oracle.render(blob, tuple(meta["crop"]), meta["spp_min"], max_bounce=meta["bounce"],
+                                        seed=meta["seed"], photon=(pp, pm, cm))
+    assert np.array_equal(bits(rgb), bits(g["rgb"]))
+    assert np.array_equal(bits(depth), bits(g["depth"]))
+    assert (cnt.casts_normal, cnt.casts_shadow) == (meta["casts_normal"], meta["casts_shadow"])
+    # the maps matter: the same frame without them is a different image
+    plain = oracle.render(blob, tuple(meta["crop"]), meta["spp_min"], max_bounce=meta["bounce"], seed=meta["seed"])[0]
+    assert not np.array_equal(bits(plain), bits(rgb))
+
+
+def test_oracle_photon_build_errors():
+    # no photon source (Cornell box: emissive plane only) / caustics map that can never fill
+    _, _, _, meta = load_golden("c2_box_64x64_4spp")
+    with pytest.raises(RuntimeError, match="-3"):
+        oracle.photon_build(golden_blob(meta), oracle.photon_params((100, 20, 0.2), (10, 20, 1.0)))
+    _, _, _, meta = load_golden("box3_48x36_4spp")
+    with pytest.raises(RuntimeError, match="-4"):
+        oracle.photon_build(golden_blob(meta), oracle.photon_params((50, 20, 0.2), (2, 20, 1.0)))
 
 
 def test_oracle_thread_count_does_not_change_pixels():
