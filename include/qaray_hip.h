@@ -20,6 +20,11 @@
  *   qa_render_strips_device        Renderer_MPI's rank-strided ThreadRender (every rank renders
  *                                  tiles rank, rank+size, ...)          src/renderers/renderer.cpp:383-387
  *   qa_request_stop / qa_clear_stop   tasking::signal_stop / signal_start  src/tasking/parallel_for.cpp:70-73
+ *   qa_photon_maps_build / clear   the photon-map block of Renderer::ComputeScene with
+ *                                  RendererParam::usePhotonMap (-use-photon-map): photon tracing,
+ *                                  power scaling, kd-tree; afterwards qa_render_* shade with
+ *                                  Scene::usePhotonMap = true        src/renderers/renderer.cpp:114-291,
+ *                                                                       src/materials/MtlBlinn_PhotonMap.cpp:349-458
  *   qa_get_counters                (no counterpart: the reference only prints wall-clock)
  *   qa_get_kernel_time             Renderer::StartTimer/StopTimer       src/renderers/renderer.cpp:42-63
  */
@@ -28,6 +33,7 @@
 
 #include <stdint.h>
 
+#include "qa_photon.h"
 #include "qaray_host.h" /* QA_OK / QA_E* */
 
 #ifdef __cplusplus
@@ -84,6 +90,24 @@ int qa_strip_count(int y0, int y1, int first_strip, int strip_step);
 /* Wait for everything enqueued by this context. */
 int qa_synchronize(qa_ctx *ctx);
 
+/* Photon / caustics maps (the reference's -use-photon-map mode).  qa_photon_maps_build traces
+ * photons from the scene's point lights on the GPU - one RNG stream per emission, see
+ * include/qa_photon.h - keeps the first params->*.size of them in the reference's order, scales
+ * their powers by 1 / emitted rays, balances each map into cyPhotonMap's kd-tree and leaves both
+ * resident in HBM; from then on qa_render_* shade with Scene::usePhotonMap = true (a DIFFUSE
+ * selection gathers 100 nearest photons from the caustics map, and from the photon map instead of
+ * bouncing after a diffuse bounce).  The maps live until qa_photon_maps_clear or the next scene
+ * upload.  Deterministic in (scene, params, seed): every rank of a multi-GPU job builds the same maps.
+ * Errors: QA_EUNSUPPORTED when the scene has no point light or a map cannot be filled within
+ * QA_PHOTON_MAX_EMISSIONS (the reference divides by zero / loops forever in these cases).
+ * qa_photon_maps_info: numOfEmittedRays and loop iterations per map ([0] photon, [1] caustics);
+ * qa_photon_maps_download: the balanced records as they sit in HBM, size + 1 entries, [0] unused
+ * ([1..size] is byte-compatible with the reference's photonmap.dat / caustics.dat dumps). */
+int qa_photon_maps_build(qa_ctx *ctx, const qa_photon_params *params, uint32_t seed);
+int qa_photon_maps_clear(qa_ctx *ctx);
+int qa_photon_maps_info(qa_ctx *ctx, uint64_t emitted[2], uint64_t emissions[2]);
+int qa_photon_maps_download(qa_ctx *ctx, int which, qa_photon *out, uint64_t capacity);
+
 int qa_request_stop(qa_ctx *ctx);
 int qa_clear_stop(qa_ctx *ctx);
 
@@ -104,6 +128,7 @@ const char *qa_last_error(void);
  * sinf/cosf evaluated on the GPU, and the same source compiled for the host (fn: 0 sinf, 1 cosf,
  * 2 powf(x,y), 3 expf). */
 int qa_test_sincosf_device(const float *x, int n, float *s, float *c);
+int qa_test_math_device(int fn, const float *x, const float *y, int n, float *out);
 int qa_test_math_host(int fn, const float *x, const float *y, int n, float *out);
 
 #ifdef __cplusplus

@@ -11,81 +11,7 @@
 #include <vector>
 
 #include "qa_kernel_sm.h"
-#include "qaray_hip.h"
-
-using namespace qa;
-
-static thread_local std::string g_err;
-static int Fail(int code, const std::string &msg) { g_err = msg; return code; }
-#define HIP_TRY(expr)                                                                          \
-  do {                                                                                         \
-    hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess) return Fail(QA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-
-struct EventPair { hipEvent_t a, b; };
-
-struct qa_ctx {
-  int device = 0;
-  int numCUs = 0;
-  hipStream_t stream = nullptr;
-  // scene
-  std::vector<unsigned char> hostBlob;
-  unsigned char *dBlob = nullptr;
-  std::vector<void *> sceneAllocs;  // derived arrays
-  DScene ds{};
-  bool haveScene = false;
-  float *dHalton = nullptr;
-  int haltonCount = 0;
-  // launch plumbing
-  static const int kCounterRing = 64;
-  unsigned int *dWork = nullptr;  // ring of work counters
-  int workNext = 0;
-  int *hStop = nullptr;           // mapped host memory, read by the kernel's wave leaders
-  int *dStopAlias = nullptr;
-  DCounters *dCounters = nullptr;
-  // host-variant staging
-  float *dRgb = nullptr, *dDepth = nullptr;
-  uint32_t *dNs = nullptr;
-  size_t stagePixels = 0;
-  // timing
-  std::vector<EventPair> pending, freeEvents;
-  double totalMs = 0;
-  uint64_t launches = 0;
-  int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
-  void (*kernel)(const DScene, const RenderParams) = nullptr;
-  void (*kernelStats)(const DScene, const RenderParams) = nullptr;
-  bool resident = false, textured = false, area = false, useSM = false;
-  int syncAuto = 0;
-  uint32_t *dOrder = nullptr;   // tile launch order of the last region shape
-  uint64_t orderKey = 0;
-  int smGen = 32, smInst = 16, smTrav = 16;
-  int syncSamples = -1;  // -1: decide per scene (SelectKernel), 0/1 forced by QA_SYNC
-  uint32_t stackDepth = 32;
-  size_t ldsBytes = 0;
-};
-
-static void FreeScene(qa_ctx *c)
-{
-  for (void *p : c->sceneAllocs) (void) hipFree(p);
-  c->sceneAllocs.clear();
-  if (c->dBlob) (void) hipFree(c->dBlob);
-  c->dBlob = nullptr;
-  c->haveScene = false;
-}
-
-template <class T>
-static int DeviceCopy(qa_ctx *c, const std::vector<T> &v, const T **out)
-{
-  *out = nullptr;
-  if (v.empty()) return QA_OK;
-  void *p = nullptr;
-  HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
-  c->sceneAllocs.push_back(p);
-  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  *out = static_cast<const T *>(p);
-  return QA_OK;
-}
+#include "qa_ctx.h"
 
 // core/sampler.cpp:31-40, evaluated on the host in the reference's fp32 order
 static float HaltonF(int index, int base)
@@ -114,7 +40,6 @@ static int EnsureHalton(qa_ctx *c, int count)
   return QA_OK;
 }
 
-typedef void (*KernelFn)(const DScene, const RenderParams);
 static const size_t kMaxLdsPerBlock = 64 * 1024;      // dynamic LDS a workgroup may ask for without opt-in
 static const size_t kResidentLdsBudget = 40 * 1024;   // image + stacks: keeps 4 workgroups per CU (160 KB LDS)
 
@@ -550,10 +475,32 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   }
   rp.stop_flag = c->dStopAlias;
   rp.counters = c->dCounters;
+  // Scene::usePhotonMap: once qa_photon_maps_build has run, frames gather from the maps
+  const bool pmOn = c->photonReady;
+  memset(rp.pm, 0, sizeof(rp.pm));
+  rp.heapD = nullptr;
+  rp.heapI = nullptr;
+  if (pmOn) {
+    for (int k = 0; k < 2; ++k) {
+      const qa_photon_map_params &mp = k ? c->photonParams.caustics : c->photonParams.photon;
+      rp.pm[k].photons = static_cast<const uint32_t *>(c->dPhotons[k]);
+      rp.pm[k].count = mp.size;
+      rp.pm[k].half = (int32_t) (mp.size / 2) - 1;   // halfStoredPhotons = (photons.size() - 1) / 2 - 1, cyPhotonMap.h:291
+      rp.pm[k].radius = mp.radius;
+    }
+    rp.heapD = static_cast<float *>(c->dHeapD);
+    rp.heapI = static_cast<uint32_t *>(c->dHeapI);
+  }
+  DScene ds = c->ds;
+  if (pmOn) ds.stackDepth = c->stackDepthPm;
+  const size_t ldsBytes = pmOn ? c->ldsBytesPm : c->ldsBytes;
+  const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
+                               : ((flags & QA_RENDER_STATS) ? c->kernelStats : c->kernel);
 
   const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ownRows;
   const long long needBlocks = ((long long) tiles * 64 + QA_BLOCK - 1) / QA_BLOCK;
-  long long blocks = (long long) c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : c->blocksPerCUAuto);
+  long long blocks = (long long) c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : (pmOn ? c->blocksPerCUPm : c->blocksPerCUAuto));
+  if (pmOn && blocks > (long long) c->numCUs * 8) blocks = (long long) c->numCUs * 8;   // the heap scratch is sized for this
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
@@ -561,8 +508,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
   else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
   HIP_TRY(hipEventRecord(ev.a, s));
-  hipLaunchKernelGGL((flags & QA_RENDER_STATS) ? c->kernelStats : c->kernel, dim3((unsigned) blocks), dim3(QA_BLOCK),
-                     (unsigned) c->ldsBytes, s, c->ds, rp);
+  hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev.b, s));
   c->pending.push_back(ev);
@@ -589,7 +535,36 @@ __global__ void qa_sincos_probe(const float *x, int n, float *s, float *c)
   if (i < n) { s[i] = qsinf(x[i]); c[i] = qcosf(x[i]); }
 }
 
+__global__ void qa_math_probe(int fn, const float *x, const float *y, int n, float *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (fn) {
+    case 0: out[i] = qsinf(x[i]); break;
+    case 1: out[i] = qcosf(x[i]); break;
+    case 2: out[i] = qpowf(x[i], y[i]); break;
+    default: out[i] = qexpf(x[i]); break;
+  }
+}
+
 extern "C" {
+
+// the device build of qa_device_math.h: fn 0 sinf, 1 cosf, 2 powf(x, y), 3 expf (host arrays in / out)
+int qa_test_math_device(int fn, const float *x, const float *y, int n, float *out)
+{
+  if (!x || !out || n <= 0 || fn < 0 || fn > 3 || (fn == 2 && !y)) return Fail(QA_EINVAL, "bad argument");
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc((void **) &dx, n * sizeof(float)));
+  HIP_TRY(hipMalloc((void **) &dy, n * sizeof(float)));
+  HIP_TRY(hipMalloc((void **) &dout, n * sizeof(float)));
+  HIP_TRY(hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice));
+  if (y) HIP_TRY(hipMemcpy(dy, y, n * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qa_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, fn, dx, dy, n, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
+  (void) hipFree(dx); (void) hipFree(dy); (void) hipFree(dout);
+  return QA_OK;
+}
 
 // Self-test hooks: the device math next to the host libm (tests/test_gpu_parity.py, tests/test_device_math.py)
 int qa_test_sincosf_device(const float *x, int n, float *s, float *c)

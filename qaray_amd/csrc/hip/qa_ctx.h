@@ -1,0 +1,102 @@
+// qa_ctx.h — internals shared by the translation units of libqaray_hip.so (qa_capi.hip: context,
+// scene, render launches; qa_photon.hip: photon / caustics maps).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "qa_scene_dev.h"
+#include "qaray_hip.h"
+
+using namespace qa;
+
+typedef void (*KernelFn)(const DScene, const RenderParams);
+
+inline thread_local std::string g_err;
+inline int Fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return Fail(QA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct qa_ctx {
+  int device = 0;
+  int numCUs = 0;
+  hipStream_t stream = nullptr;
+  // scene
+  std::vector<unsigned char> hostBlob;
+  unsigned char *dBlob = nullptr;
+  std::vector<void *> sceneAllocs;  // derived arrays
+  DScene ds{};
+  bool haveScene = false;
+  float *dHalton = nullptr;
+  int haltonCount = 0;
+  // launch plumbing
+  static const int kCounterRing = 64;
+  unsigned int *dWork = nullptr;  // ring of work counters
+  int workNext = 0;
+  int *hStop = nullptr;           // mapped host memory, read by the kernel's wave leaders
+  int *dStopAlias = nullptr;
+  DCounters *dCounters = nullptr;
+  // host-variant staging
+  float *dRgb = nullptr, *dDepth = nullptr;
+  uint32_t *dNs = nullptr;
+  size_t stagePixels = 0;
+  // timing
+  std::vector<EventPair> pending, freeEvents;
+  double totalMs = 0;
+  uint64_t launches = 0;
+  int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
+  void (*kernel)(const DScene, const RenderParams) = nullptr;
+  void (*kernelStats)(const DScene, const RenderParams) = nullptr;
+  bool resident = false, textured = false, area = false, useSM = false;
+  int syncAuto = 0;
+  uint32_t *dOrder = nullptr;   // tile launch order of the last region shape
+  uint64_t orderKey = 0;
+  int smGen = 32, smInst = 16, smTrav = 16;
+  int syncSamples = -1;  // -1: decide per scene (SelectKernel), 0/1 forced by QA_SYNC
+  uint32_t stackDepth = 32;
+  size_t ldsBytes = 0;
+  // photon / caustics maps (qa_photon.hip); valid until the next scene upload or qa_photon_maps_clear
+  bool photonReady = false;
+  KernelFn kernelPm = nullptr, kernelPmStats = nullptr;
+  int blocksPerCUPm = 2;
+  uint32_t stackDepthPm = 0;   // LDS stack entries per lane when the kd-tree gather runs on it
+  size_t ldsBytesPm = 0;
+  void *dPhotons[2] = {nullptr, nullptr};
+  void *dHeapD = nullptr, *dHeapI = nullptr;
+  qa_photon_params photonParams{};
+  uint64_t photonEmitted[2] = {0, 0}, photonEmissions[2] = {0, 0};
+  std::vector<qa_photon> hostPhotons[2];   // balanced, [0] unused
+};
+
+void FreePhotonMaps(qa_ctx *c);  // qa_photon.hip
+
+inline void FreeScene(qa_ctx *c)
+{
+  FreePhotonMaps(c);
+  for (void *p : c->sceneAllocs) (void) hipFree(p);
+  c->sceneAllocs.clear();
+  if (c->dBlob) (void) hipFree(c->dBlob);
+  c->dBlob = nullptr;
+  c->haveScene = false;
+}
+
+template <class T>
+inline int DeviceCopy(qa_ctx *c, const std::vector<T> &v, const T **out)
+{
+  *out = nullptr;
+  if (v.empty()) return QA_OK;
+  void *p = nullptr;
+  HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+  c->sceneAllocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T *>(p);
+  return QA_OK;
+}
+

@@ -147,16 +147,135 @@ __host__ __device__ __forceinline__ void sincos_f64(double x, double *s, double 
   *c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// powf for the integrator's domain (base >= 0): (float) 2^(y * log2(x)) in fp64.
+// ---------------------------------------------------------------------------------------------
+// expf / powf: the algorithms glibc >= 2.28 uses (Arm Optimized Routines' expf and powf: table-
+// driven 2^(k/32) with a cubic in fp64; powf takes log2(x) from a 16-entry table plus a degree-5
+// polynomial), restated with the published tables.  Every a*b+c below is a fused multiply-add
+// where glibc's x86-64 build for FMA-capable CPUs (the ifunc variant __expf_fma / __powf_fma that
+// the host runs, here and on the GPU box) fuses it, and a separate multiply and add where it does
+// not, so that the device returns the bits the reference's libm calls return.
+// tests/test_device_math.py compares both with the host libm (expf over every float; powf over
+// random pairs and over the integrator's exponents).
+// ---------------------------------------------------------------------------------------------
+namespace mathtab {
+// 2^(i/32) as a double bit pattern minus (i << 47): adding (k << 47) yields 2^(k/32) for any int k
+constexpr uint64_t kExp2[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+// log2 table: for the 16 sub-intervals of [0x1.66p-1, 0x1.66p0): 1/c and log2(c)
+constexpr double kLog2[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+}  // namespace mathtab
+
+__host__ __device__ __forceinline__ double qa_asdouble(uint64_t u)
+{
+  double d;
+  __builtin_memcpy(&d, &u, 8);
+  return d;
+}
+__host__ __device__ __forceinline__ uint64_t qa_asuint64(double d)
+{
+  uint64_t u;
+  __builtin_memcpy(&u, &d, 8);
+  return u;
+}
+__host__ __device__ __forceinline__ uint32_t qa_asuint(float f)
+{
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+
+__host__ __device__ __forceinline__ float qexpf(float x)
+{
+  const uint32_t abstop = (qa_asuint(x) >> 20) & 0x7ff;
+  if (abstop >= 0x42b) {   // |x| >= 88 or NaN: the special cases of the original
+    if (qa_asuint(x) == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();   // overflow
+    if (x < -0x1.9fe368p6f) return 0.0f;              // underflow
+  }
+  const double xd = (double) x;
+  const double InvLn2N = 0x1.71547652b82fep+5, SHIFT = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+  // x * N/ln2 = k + r, r in [-1/2, 1/2]
+  double kd = __builtin_fma(InvLn2N, xd, SHIFT);
+  const uint64_t ki = qa_asuint64(kd);
+  kd -= SHIFT;
+  const double r = __builtin_fma(InvLn2N, xd, -kd);
+  const double s = qa_asdouble(mathtab::kExp2[ki % 32] + (ki << 47));
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  return (float) (y * s);
+}
+
+// powf for a non-negative base (all the integrator needs: cosines, 1 - |cos|, cone ratios)
 __host__ __device__ __forceinline__ float qpowf(float x, float y)
 {
   if (y == 0.f) return 1.f;
   if (x == 1.f) return 1.f;
   if (x == 0.f) return y > 0.f ? 0.f : __builtin_inff();
-  if (y == 1.f) return x;
-  return (float) exp2((double) y * log2((double) x));
+  if (!(x > 0.f) || !(x < __builtin_inff()) || !(y == y) || y == __builtin_inff() || y == -__builtin_inff())
+    return (float) exp2((double) y * log2((double) x));  // outside the restated domain: not reached by the integrator
+  uint32_t ix = qa_asuint(x);
+  if (ix < 0x00800000u) {  // subnormal base: normalise
+    ix = qa_asuint(x * 0x1p23f);
+    ix &= 0x7fffffffu;
+    ix -= 23u << 23;
+  }
+  // log2(x) = log1p(z/c - 1)/ln2 + log2(c) + k
+  const uint32_t tmp = ix - 0x3f330000u;
+  const uint32_t i = (tmp >> 19) % 16;
+  const uint32_t top = tmp & 0xff800000u;
+  const uint32_t iz = ix - top;
+  const int k = (int32_t) top >> 23;
+  const double invc = mathtab::kLog2[i][0], logc = mathtab::kLog2[i][1];
+  float zf;
+  __builtin_memcpy(&zf, &iz, 4);
+  const double z = (double) zf;
+  const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+               A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp+0;
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = logc + (double) k;
+  const double r2 = r * r;
+  double yy = __builtin_fma(A0, r, A1);
+  const double p = __builtin_fma(A2, r, A3);
+  const double r4 = r2 * r2;
+  double q = __builtin_fma(A4, r, y0);
+  q = __builtin_fma(p, r2, q);
+  yy = __builtin_fma(yy, r4, q);
+  const double ylogx = (double) y * yy;
+  if (((qa_asuint64(ylogx) >> 47) & 0xffff) >= (qa_asuint64(126.0) >> 47)) {
+    if (ylogx > 0x1.fffffffd1d571p+6) return __builtin_inff();  // |y*log(x)| >= 126: overflow ...
+    if (ylogx <= -150.0) return 0.0f;                            // ... or underflow
+  }
+  // 2^ylogx: N*x = k + r
+  const double SHIFT = 0x1.8p+47;
+  const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+  double kd = ylogx + SHIFT;
+  const uint64_t ki = qa_asuint64(kd);
+  kd -= SHIFT;
+  const double rr = ylogx - kd;
+  const double s = qa_asdouble(mathtab::kExp2[ki % 32] + (ki << 47));
+  const double zz = __builtin_fma(C0, rr, C1);
+  const double rr2 = rr * rr;
+  double e = __builtin_fma(C2, rr, 1.0);
+  e = __builtin_fma(zz, rr2, e);
+  return (float) (e * s);
 }
-__host__ __device__ __forceinline__ float qexpf(float x) { return (float) exp((double) x); }
 __host__ __device__ __forceinline__ float qasinf(float x) { return (float) asin((double) x); }
 __host__ __device__ __forceinline__ float qtanf(float x) { return (float) tan((double) x); }
 

@@ -63,6 +63,10 @@ struct SceneMem {
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
+}  // namespace qa
+#include "qa_photon_dev.h"   // needs QA_BLOCK and asF
+namespace qa {
+
 // Scene-graph nodes and mesh descriptors: resident scenes carry them BY VALUE in the kernel
 // arguments (constant address space: wave-uniform indices become scalar loads into SGPRs, no
 // vector-memory round trip on the critical path of every cast); larger scenes read the tables
@@ -643,6 +647,7 @@ struct Surface {
   bool spawn;            // a secondary ray follows
   f3 nextDir, bxdf;      // its (un-normalised) direction and the BxDF weight (PDF = 1)
   bool nextFromDiffuse;
+  bool selDiffuse;       // RandomSelectMtl returned DIFFUSE (photon-map gathers hang off this)
 };
 
 template <bool TEX>
@@ -765,6 +770,7 @@ __device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const DSc
   o.nextDir = nextDir;
   o.bxdf = bxdf;
   o.nextFromDiffuse = nextFromDiffuse;
+  o.selDiffuse = (select == 2);
   return o;
 }
 
@@ -792,7 +798,11 @@ struct Path {
 #define QA_MAX_PATH 8           /* hits per path an AREA variant can log (maxBounce <= 7) */
 #define QA_REC_FLOATS 19
 
-template <bool RES, bool LIGHTS, bool TEX, bool AREA, bool STATS>
+// PHOTON variants (Scene::usePhotonMap, -use-photon-map): a DIFFUSE selection gathers from the
+// caustics map, and from the photon map instead of bouncing when the ray already comes from a
+// diffuse bounce (MtlBlinn_PhotonMap.cpp:349-359,426-458).  The gathers draw no random numbers, so
+// they are evaluated at the hit (also by AREA variants).
+template <bool RES, bool LIGHTS, bool TEX, bool AREA, bool STATS, bool PHOTON = false>
 __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -985,6 +995,15 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
           const bool spawn = sf.spawn;
           const f3 nextDir = sf.nextDir, bxdf = sf.bxdf;
           const bool nextFromDiffuse = sf.nextFromDiffuse;
+
+          if (PHOTON && sf.selDiffuse) {
+            const size_t hstride = (size_t) gridDim.x * QA_BLOCK;
+            float *hd = rp.heapD + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+            uint32_t *hi = rp.heapI + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+            if (path.fromDiffuse)
+              path.L = path.L + path.T * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, hd, hi, hstride);
+            path.L = path.L + path.T * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, hd, hi, hstride);
+          }
 
           // direct lighting (:481-498)
           if (LIGHTS && !AREA) {

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "qa_flat_scene.h"
+#include "qa_photon.h"
 
 namespace qa {
 
@@ -119,6 +120,16 @@ struct DCounters {
   unsigned long long samples, casts_normal, casts_shadow, bvh_nodes, tri_tests, pixels;
 };
 
+// One balanced photon map in HBM (qa_photon records of include/qa_photon.h read as 6 dwords each;
+// [0] unused, [1..count] the kd-tree in heap order, cyPhotonMap.h:272-292)
+struct DPhotonMap {
+  const uint32_t *photons;
+  int32_t half;       // PhotonMap::halfStoredPhotons
+  uint32_t count;
+  float radius;
+  uint32_t pad;
+};
+
 struct RenderParams {
   int32_t x0, y0, x1, y1;      // region
   int32_t spp_min, spp_max, max_bounce;
@@ -133,6 +144,11 @@ struct RenderParams {
   unsigned int *work_counter;  // next work item (pixel) of this launch
   const volatile int *stop_flag;
   DCounters *counters;
+  // PHOTON kernel variants (Scene::usePhotonMap): [0] photon map, [1] caustics map, and the per-lane
+  // nearest-photon heaps ([QA_PHOTON_GATHER + 1][grid threads] distances / photon indices)
+  DPhotonMap pm[2];
+  float *heapD;
+  uint32_t *heapI;
 };
 
 }  // namespace qa

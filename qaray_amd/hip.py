@@ -21,6 +21,19 @@ class Counters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class PhotonMapParams(C.Structure):   # include/qa_photon.h
+    _fields_ = [("size", C.c_uint32), ("bounce", C.c_uint32), ("radius", C.c_float)]
+
+
+class PhotonParams(C.Structure):
+    _fields_ = [("photon", PhotonMapParams), ("caustics", PhotonMapParams)]
+
+
+# qa_photon: byte-compatible with the reference's cy::PhotonMap::Photon (24 bytes)
+PHOTON_DTYPE = np.dtype([("pos", np.float32, 3), ("power", np.float32), ("rgb", np.uint8, 3), ("plane_dirz", np.uint8),
+                         ("dirx", np.int16), ("diry", np.int16)])
+
+
 class HipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libqaray_hip error {code}: {msg}")
@@ -57,6 +70,10 @@ def lib():
         L.qa_get_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.qa_reset_kernel_time.argtypes = [C.c_void_p]
         L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.qa_photon_maps_build.argtypes = [C.c_void_p, C.POINTER(PhotonParams), C.c_uint32]
+        L.qa_photon_maps_clear.argtypes = [C.c_void_p]
+        L.qa_photon_maps_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.qa_photon_maps_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -96,6 +113,29 @@ class Context:
         # qa_flat_header: width/height follow magic,version(8) total_bytes(8) 6 vec3 (72) dof (4)
         w, h = np.frombuffer(bytes(bytearray(blob_head[92:100])), dtype=np.uint32)
         self.size = (int(w), int(h))
+
+    # -- photon / caustics maps (the reference's -use-photon-map) ---------------------------------
+    def build_photon_maps(self, photon=(10000, 20, 0.2), caustics=(1000, 20, 1.0), seed=DEFAULT_SEED):
+        """Trace and balance both maps on the GPU; later renders shade with Scene::usePhotonMap = true.
+        photon / caustics: (size, bounce, radius), defaults = RendererParam (src/renderers/renderer.h:51-57)."""
+        pp = PhotonParams(PhotonMapParams(*photon), PhotonMapParams(*caustics))
+        _check(lib().qa_photon_maps_build(self._h, C.byref(pp), seed))
+        self._photon_sizes = (int(photon[0]), int(caustics[0]))
+
+    def clear_photon_maps(self):
+        _check(lib().qa_photon_maps_clear(self._h))
+
+    def photon_maps_info(self):
+        """-> (emitted[2], emissions[2]): numOfEmittedRays and emission-loop iterations per map."""
+        emitted, emissions = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        _check(lib().qa_photon_maps_info(self._h, emitted, emissions))
+        return list(emitted), list(emissions)
+
+    def download_photon_map(self, which):
+        """-> the balanced qa_photon records as they sit in HBM, size + 1 entries ([0] unused)."""
+        out = np.zeros(self._photon_sizes[which] + 1, PHOTON_DTYPE)
+        _check(lib().qa_photon_maps_download(self._h, which, out.ctypes.data, out.size))
+        return out
 
     # -- rendering -----------------------------------------------------------------------------
     def render_region(self, region, spp, max_bounce=5, seed=DEFAULT_SEED, spp_max=None, stats=False):
