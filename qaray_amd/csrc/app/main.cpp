@@ -1,6 +1,8 @@
 // qaray_hip — batch driver with the reference's command line (src/main.cpp:8-62):
-//   qaray_hip [-batch] [-spp N] [-sppMin N] [-sppMax N] [-bounce N] [-srgb 0|1] [-threads N] scene.xml
-// plus what the reference has no flag for: -size W H, -seed S, -device D, -out PREFIX, -root DIR.
+//   qaray_hip [-batch] [-spp N] [-sppMin N] [-sppMax N] [-bounce N] [-srgb 0|1] [-threads N]
+//             [-use-photon-map] [-photon-map-size N] [-caustics-map-size N] scene.xml
+// plus what the reference has no flag for: -size W H, -seed S, -device D, -out PREFIX, -root DIR,
+// -photon-map-radius R, -caustics-map-radius R, -photon-map-bounce N, -caustics-map-bounce N.
 // The reference's `-sppMax` sets sppMin by mistake (main.cpp:27-28); here it sets sppMax.
 // Flow: Init -> LoadScene -> ComputeScene -> Render -> Terminate (main.cpp:55-59).
 #include <cstdio>
@@ -29,6 +31,13 @@ int main(int argc, char **argv)
     else if (s == "-bounce") Material::maxBounce = atoi(next());
     else if (s == "-srgb") param.SetSRGBFlag(atoi(next()) != 0);
     else if (s == "-threads") (void) next();  // CPU thread count has no meaning here
+    else if (s == "-use-photon-map") param.SetPhotonMappingFlag(true);
+    else if (s == "-photon-map-size") param.SetPhotonMapSize((size_t) atoi(next()));
+    else if (s == "-caustics-map-size") param.SetCausticsMapSize((size_t) atoi(next()));
+    else if (s == "-photon-map-radius") param.SetPhotonMapRadius((float) atof(next()));
+    else if (s == "-caustics-map-radius") param.SetCausticsMapRadius((float) atof(next()));
+    else if (s == "-photon-map-bounce") param.SetPhotonMapBounce((size_t) atoi(next()));
+    else if (s == "-caustics-map-bounce") param.SetCausticsMapBounce((size_t) atoi(next()));
     else if (s == "-size") { w = atoi(next()); h = atoi(next()); }
     else if (s == "-seed") param.seed = (uint32_t) strtoul(next(), nullptr, 0);
     else if (s == "-device") device = atoi(next());

@@ -33,6 +33,24 @@ void Renderer::ComputeScene(FrameBuffer &fb, Scene &sc)
   const std::vector<unsigned char> blob = FlattenScene(sc);
   if (qa_scene_upload(ctx, blob.data(), blob.size()) != QA_OK)
     throw std::runtime_error(std::string("qa_scene_upload: ") + qa_last_error());
+  // src/renderers/renderer.cpp:114-291: both maps, when asked for and non-empty
+  if (param.usePhotonMap && param.photonMapSize > 0 && param.causticsMapSize > 0) {
+    const auto t0 = std::chrono::system_clock::now();
+    qa_photon_params pp;
+    pp.photon.size = (uint32_t) param.photonMapSize;
+    pp.photon.bounce = (uint32_t) param.photonMapBounce;
+    pp.photon.radius = param.photonMapRadius;
+    pp.caustics.size = (uint32_t) param.causticsMapSize;
+    pp.caustics.bounce = (uint32_t) param.causticsMapBounce;
+    pp.caustics.radius = param.causticsMapRadius;
+    if (qa_photon_maps_build(ctx, &pp, param.seed) != QA_OK)
+      throw std::runtime_error(std::string("qa_photon_maps_build: ") + qa_last_error());
+    uint64_t emitted[2], emissions[2];
+    qa_photon_maps_info(ctx, emitted, emissions);
+    const std::chrono::duration<double> dt = std::chrono::system_clock::now() - t0;
+    printf("\nPhoton Map (%zu photons, %llu emitted rays) and Caustics Map (%zu, %llu) Take %f s to Build\n", param.photonMapSize,
+           (unsigned long long) emitted[0], param.causticsMapSize, (unsigned long long) emitted[1], dt.count());
+  }
 }
 
 // src/renderers/renderer.cpp:42-63

@@ -19,14 +19,28 @@
 
 namespace qaray_hip {
 
-struct RendererParam {  // src/renderers/renderer.h:47-68 (photon-map knobs are out of scope)
+struct RendererParam {  // src/renderers/renderer.h:47-68
   bool useSRGB = true;
   size_t sppMax = 8;
   size_t sppMin = 4;
   uint32_t seed = 0x51A7A7;
+  bool usePhotonMap = false;
+  size_t photonMapSize = 10000;
+  size_t photonMapBounce = 20;
+  float photonMapRadius = 0.2f;
+  size_t causticsMapSize = 1000;
+  size_t causticsMapBounce = 20;
+  float causticsMapRadius = 1.0f;
   void SetSPPMax(int spp) { sppMax = static_cast<size_t>(spp); }
   void SetSPPMin(int spp) { sppMin = static_cast<size_t>(spp); }
   void SetSRGBFlag(bool flag) { useSRGB = flag; }
+  void SetPhotonMappingFlag(bool flag) { usePhotonMap = flag; }
+  void SetPhotonMapBounce(size_t b) { photonMapBounce = b; }
+  void SetPhotonMapSize(size_t sz) { photonMapSize = sz; }
+  void SetPhotonMapRadius(float r) { photonMapRadius = r; }
+  void SetCausticsMapBounce(size_t b) { causticsMapBounce = b; }
+  void SetCausticsMapSize(size_t sz) { causticsMapSize = sz; }
+  void SetCausticsMapRadius(float r) { causticsMapRadius = r; }
 };
 
 class Renderer {
@@ -34,7 +48,7 @@ class Renderer {
   explicit Renderer(RendererParam &param, int device = 0, size_t rank = 0, size_t size = 1);
   virtual ~Renderer();
   virtual void Init();                                  // creates the HIP context
-  void ComputeScene(FrameBuffer &renderImage, Scene &scene);  // camera frame, fb, scene upload
+  void ComputeScene(FrameBuffer &renderImage, Scene &scene);  // camera frame, fb, scene upload, photon maps
   virtual void Render();                                // ThreadRender + image dumps (batch mode)
   void ThreadRender();                                  // the hot path: one HIP call
   virtual void StartTimer();

@@ -145,3 +145,31 @@ def test_photon_build_errors(ctx):
     # a failed build leaves the context usable, without maps
     rgb = ctx.render_region((0, 0, 48, 36), 1)[0]
     assert np.isfinite(rgb).all()
+
+
+def test_cli_use_photon_map_matches_python_path(tmp_path):
+    """qaray_hip -use-photon-map (the reference's flag, src/main.cpp:35-40) = build_photon_maps + render."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from qaray_amd import hip
+    from qaray_amd.host import FrameBuffer, load_scene_blob, SCENES_DIR
+    exe = os.path.join(ROOT, "qaray_amd", "lib", "qaray_hip")
+    out = str(tmp_path) + "/"
+    r = subprocess.run([exe, "-batch", "-spp", "2", "-size", "64", "48", "-root", SCENES_DIR, "-out", out, "-use-photon-map",
+                        "-photon-map-size", "3000", "-caustics-map-size", "400", os.path.join(SCENES_DIR, "custom_photon.xml")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "Photon Map (3000 photons" in r.stdout and "Caustics Map (400" in r.stdout
+    c = hip.Context(0)
+    try:
+        c.upload_scene(load_scene_blob("custom_photon.xml", size=(64, 48)))
+        c.build_photon_maps((3000, 20, 0.2), (400, 20, 1.0))
+        rgb, depth, ns = c.render_region((0, 0, 64, 48), 2)
+        fb = FrameBuffer(64, 48)
+        fb.deposit(0, 0, 64, 48, rgb, depth, ns, 2, use_srgb=True)
+        ref = str(tmp_path / "py.png")
+        fb.save_image(ref)
+        assert open(out + "colorBuffer.png", "rb").read() == open(ref, "rb").read()
+    finally:
+        c.close()
