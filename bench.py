@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, "
                          "collectives go through host memory)")
+    ap.add_argument("--photon-map", type=float, nargs=6, default=None, metavar=("N", "BOUNCE", "RADIUS", "CN", "CBOUNCE", "CRADIUS"),
+                    help="probe mode (not the headline workload): build photon / caustics maps first (-use-photon-map), "
+                         "e.g. --photon-map 10000 20 0.2 1000 20 1.0")
     ap.add_argument("--check", action="store_true",
                     help="rank 0: also render the whole frame alone and require the gathered image to equal it bit for bit")
     args = ap.parse_args()
@@ -129,6 +132,9 @@ def main():
     else:
         dblob = torch.from_numpy(blob).to(device)
     ctx.upload_scene_device(dblob)
+    if args.photon_map:
+        pm = args.photon_map   # every rank builds the same maps (deterministic in scene, parameters and seed)
+        ctx.build_photon_maps((int(pm[0]), int(pm[1]), pm[2]), (int(pm[3]), int(pm[4]), pm[5]), seed=args.seed)
 
     nstrips = hip.strip_count(0, H, rank, world)
     maxstrips = qd.max_strips_per_rank(H, world)
@@ -195,8 +201,11 @@ def main():
             "value": msamples, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"inputs/{os.path.basename(scene_xml)} (Cornell box, tinyobjloader cornell_box.obj, 36 triangles)"
-                                   f", {W}x{H}, {args.spp} spp, maxBounce {args.bounce}, seed {args.seed:#x}",
+            "config": {"workload": f"inputs/{os.path.basename(scene_xml)} "
+                                   + ("(Cornell box, tinyobjloader cornell_box.obj, 36 triangles)"
+                                      if os.path.basename(scene_xml) == "example_project12_box.xml" else "(probe scene, not the headline workload)")
+                                   + (f", photon maps {args.photon_map}" if args.photon_map else "")
+                                   + f", {W}x{H}, {args.spp} spp, maxBounce {args.bounce}, seed {args.seed:#x}",
                        "frame": [W, H], "spp": args.spp, "partition": f"8-row strips round-robin over {world} GPU(s)",
                        "wall_clock_s_per_frame": ms_per_step * 1e-3,
                        "casts_per_sample": (casts_n + casts_s) / max(samples, 1)},

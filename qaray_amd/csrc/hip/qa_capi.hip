@@ -478,18 +478,18 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   // Scene::usePhotonMap: once qa_photon_maps_build has run, frames gather from the maps
   const bool pmOn = c->photonReady;
   memset(rp.pm, 0, sizeof(rp.pm));
-  rp.heapD = nullptr;
-  rp.heapI = nullptr;
+  rp.heap = nullptr;
   if (pmOn) {
     for (int k = 0; k < 2; ++k) {
       const qa_photon_map_params &mp = k ? c->photonParams.caustics : c->photonParams.photon;
-      rp.pm[k].photons = static_cast<const uint32_t *>(c->dPhotons[k]);
+      rp.pm[k].node = static_cast<const uint4 *>(c->dPmTables[k][0]);
+      rp.pm[k].dir = static_cast<const float4 *>(c->dPmTables[k][1]);
+      rp.pm[k].power = static_cast<const float4 *>(c->dPmTables[k][2]);
       rp.pm[k].count = mp.size;
       rp.pm[k].half = (int32_t) (mp.size / 2) - 1;   // halfStoredPhotons = (photons.size() - 1) / 2 - 1, cyPhotonMap.h:291
       rp.pm[k].radius = mp.radius;
     }
-    rp.heapD = static_cast<float *>(c->dHeapD);
-    rp.heapI = static_cast<uint32_t *>(c->dHeapI);
+    rp.heap = static_cast<uint2 *>(c->dHeap);
   }
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;

@@ -68,8 +68,9 @@ struct qa_ctx {
   int blocksPerCUPm = 2;
   uint32_t stackDepthPm = 0;   // LDS stack entries per lane when the kd-tree gather runs on it
   size_t ldsBytesPm = 0;
-  void *dPhotons[2] = {nullptr, nullptr};
-  void *dHeapD = nullptr, *dHeapI = nullptr;
+  void *dPhotons[2] = {nullptr, nullptr};      // qa_photon records (what qa_photon_maps_download returns)
+  void *dPmTables[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // DPhotonMap node / dir / power
+  void *dHeap = nullptr;
   qa_photon_params photonParams{};
   uint64_t photonEmitted[2] = {0, 0}, photonEmissions[2] = {0, 0};
   std::vector<qa_photon> hostPhotons[2];   // balanced, [0] unused

@@ -998,11 +998,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DSc
 
           if (PHOTON && sf.selDiffuse) {
             const size_t hstride = (size_t) gridDim.x * QA_BLOCK;
-            float *hd = rp.heapD + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
-            uint32_t *hi = rp.heapI + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+            uint2 *heap = rp.heap + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
             if (path.fromDiffuse)
-              path.L = path.L + path.T * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, hd, hi, hstride);
-            path.L = path.L + path.T * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, hd, hi, hstride);
+              path.L = path.L + path.T * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap, hstride);
+            path.L = path.L + path.T * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap, hstride);
           }
 
           // direct lighting (:481-498)

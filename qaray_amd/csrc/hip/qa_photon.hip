@@ -379,6 +379,28 @@ void Balance(std::vector<qa_photon> &work)
   work.swap(tree);
 }
 
+// Photon::GetDirection (cyPhotonMap.h:233-254): x, y from the two shorts; z from x ALONE - the
+// reference computes "dirX*dirX + dirY - dirY" - through a digit-by-digit integer square root.
+void PhotonDirection(const qa_photon &ph, float out[3])
+{
+  out[0] = (float) ph.dirx / (float) 0x7FFF;
+  out[1] = (float) ph.diry / (float) 0x7FFF;
+  int xy2 = ph.dirx * ph.dirx + ph.diry - ph.diry;
+  if (xy2 > 0x3FFF0001) xy2 = 0x3FFF0001;
+  int root = 0, bit = 0x40000000, rem = 0x3FFF0001 - xy2;
+  while (bit > rem) bit >>= 2;
+  while (bit) {
+    if (rem >= root + bit) {
+      rem = rem - root - bit;
+      root = root + (bit << 1);
+    }
+    root >>= 1;
+    bit >>= 2;
+  }
+  out[2] = (float) root / (float) 0x7FFF;
+  if (ph.plane_dirz & 0x8) out[2] = -out[2];
+}
+
 struct Scratch {   // device buffers of one build, released on every exit path
   std::vector<void *> ptrs;
   ~Scratch() { for (void *p : ptrs) (void) hipFree(p); }
@@ -398,12 +420,15 @@ void FreePhotonMaps(qa_ctx *c)
   for (int k = 0; k < 2; ++k) {
     if (c->dPhotons[k]) (void) hipFree(c->dPhotons[k]);
     c->dPhotons[k] = nullptr;
+    for (int t = 0; t < 3; ++t) {
+      if (c->dPmTables[k][t]) (void) hipFree(c->dPmTables[k][t]);
+      c->dPmTables[k][t] = nullptr;
+    }
     c->hostPhotons[k].clear();
     c->photonEmitted[k] = c->photonEmissions[k] = 0;
   }
-  if (c->dHeapD) (void) hipFree(c->dHeapD);
-  if (c->dHeapI) (void) hipFree(c->dHeapI);
-  c->dHeapD = c->dHeapI = nullptr;
+  if (c->dHeap) (void) hipFree(c->dHeap);
+  c->dHeap = nullptr;
   c->photonReady = false;
 }
 
@@ -459,6 +484,32 @@ static int BuildOne(qa_ctx *c, int which, const qa_photon_map_params &mp, uint32
   try { Balance(host); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
   HIP_TRY(hipMalloc(&c->dPhotons[which], host.size() * sizeof(qa_photon)));
   HIP_TRY(hipMemcpy(c->dPhotons[which], host.data(), host.size() * sizeof(qa_photon), hipMemcpyHostToDevice));
+  // the gather's tables (DPhotonMap): what Photon::GetPlane / GetDirection / GetMaxPower / GetPower return
+  {
+    std::vector<float> tab;
+    try { tab.resize(host.size() * 4); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+    for (int t = 0; t < 3; ++t) {
+      for (size_t i = 0; i < host.size(); ++i) {
+        const qa_photon &ph = host[i];
+        float *o = &tab[4 * i];
+        if (t == 0) {
+          const uint32_t axis = ph.plane_dirz & 0x3u;
+          o[0] = ph.pos[0]; o[1] = ph.pos[1]; o[2] = ph.pos[2];
+          memcpy(&o[3], &axis, 4);
+        } else if (t == 1) {
+          PhotonDirection(ph, o);
+          o[3] = ph.power;
+        } else {
+          o[0] = (ph.rgb[0] / 255.0f) * ph.power;   // ToColor(color) * power, src/math/math.h:119-123
+          o[1] = (ph.rgb[1] / 255.0f) * ph.power;
+          o[2] = (ph.rgb[2] / 255.0f) * ph.power;
+          o[3] = 0.f;
+        }
+      }
+      HIP_TRY(hipMalloc(&c->dPmTables[which][t], tab.size() * sizeof(float)));
+      HIP_TRY(hipMemcpy(c->dPmTables[which][t], tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
   c->photonEmitted[which] = state[1];
   c->photonEmissions[which] = state[2];
   return QA_OK;
@@ -495,10 +546,10 @@ int qa_photon_maps_build(qa_ctx *c, const qa_photon_params *pp, uint32_t seed)
     if (light[i].type == QA_LIGHT_POINT) sources.push_back((int32_t) i);
   if (sources.empty())
     return Fail(QA_EUNSUPPORTED, "photon map: the scene has no point light (the reference divides by zero photon sources)");
-  // the gather walks the kd-tree on the lane's LDS stack: one (node, phase) word per level + 1
+  // the gather walks the kd-tree on the lane's LDS stack: two words per tree level + 1
   uint32_t levels = 1;
   for (uint32_t n = std::max(pp->photon.size, pp->caustics.size); n > 1; n >>= 1) ++levels;
-  const uint32_t needDepth = std::max(c->stackDepth, levels + 2);
+  const uint32_t needDepth = std::max(c->stackDepth, 2 * (levels + 2));
   const size_t stackBytes = ((size_t) needDepth + 6) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = c->resident ? (size_t) c->ds.residentVec4 * sizeof(uint4) : 0;
   if (imageBytes + stackBytes > 64 * 1024) return Fail(QA_EUNSUPPORTED, "photon map too deep for the LDS stack");
@@ -522,9 +573,8 @@ int qa_photon_maps_build(qa_ctx *c, const qa_photon_params *pp, uint32_t seed)
   c->blocksPerCUPm = resident > 8 ? 8 : resident;
   // nearest-photon heaps: QA_PHOTON_GATHER + 1 slots per thread of the largest grid
   const size_t threads = (size_t) c->numCUs * 8 * QA_BLOCK;
-  hipError_t e;
-  if ((e = hipMalloc(&c->dHeapD, threads * (QA_PHOTON_GATHER + 1) * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc(&c->dHeapI, threads * (QA_PHOTON_GATHER + 1) * sizeof(uint32_t))) != hipSuccess) {
+  const hipError_t e = hipMalloc(&c->dHeap, threads * (QA_PHOTON_GATHER + 1) * sizeof(uint2));
+  if (e != hipSuccess) {
     FreePhotonMaps(c);
     return Fail(QA_EHIP, std::string("photon heaps: ") + hipGetErrorString(e));
   }

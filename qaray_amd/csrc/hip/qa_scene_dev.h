@@ -120,10 +120,18 @@ struct DCounters {
   unsigned long long samples, casts_normal, casts_shadow, bvh_nodes, tri_tests, pixels;
 };
 
-// One balanced photon map in HBM (qa_photon records of include/qa_photon.h read as 6 dwords each;
-// [0] unused, [1..count] the kd-tree in heap order, cyPhotonMap.h:272-292)
+// One balanced photon map in HBM: [0] unused, [1..count] the kd-tree in heap order
+// (cyPhotonMap.h:272-292).  Next to the byte-compatible qa_photon records the build keeps what the
+// gather needs in three 16-byte tables, with everything cy::PhotonMap::Photon decodes on every
+// access (GetDirection's integer square root and divisions, GetPower's colour * power) evaluated
+// once per photon on the host with the same fp32 operations:
+//   node[i]  = (position.xyz, split axis)            read at every visited node
+//   dir[i]   = (direction.xyz, GetMaxPower())        read for photons inside the search radius
+//   power[i] = (GetPower() rgb, -)                   read for the <= 100 photons that are summed
 struct DPhotonMap {
-  const uint32_t *photons;
+  const uint4 *node;
+  const float4 *dir;
+  const float4 *power;
   int32_t half;       // PhotonMap::halfStoredPhotons
   uint32_t count;
   float radius;
@@ -145,10 +153,9 @@ struct RenderParams {
   const volatile int *stop_flag;
   DCounters *counters;
   // PHOTON kernel variants (Scene::usePhotonMap): [0] photon map, [1] caustics map, and the per-lane
-  // nearest-photon heaps ([QA_PHOTON_GATHER + 1][grid threads] distances / photon indices)
+  // nearest-photon heaps ([QA_PHOTON_GATHER + 1][grid threads] x (distance^2, photon index))
   DPhotonMap pm[2];
-  float *heapD;
-  uint32_t *heapI;
+  uint2 *heap;
 };
 
 }  // namespace qa

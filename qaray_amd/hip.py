@@ -50,6 +50,14 @@ def lib():
             raise RuntimeError(
                 f"{HIP_LIB_PATH} is missing: the HIP extension is the product path and has no fallback - "
                 "build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C qaray_amd/csrc hip`")
+        # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one
+        # process do not share the device: whichever initialises second reports "No HIP GPUs are
+        # available".  Loading torch first makes libqaray_hip.so bind to the runtime torch already
+        # loaded, so device pointers and streams can be exchanged; without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(HIP_LIB_PATH)
         L.qa_last_error.restype = C.c_char_p
         L.qa_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
