@@ -142,11 +142,22 @@ def main():
     rgb = torch.zeros((rows, W, 3), dtype=torch.float32, device=device)
     depth = torch.zeros((rows, W), dtype=torch.float32, device=device)
     ns = torch.zeros((rows, W), dtype=torch.int32, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
+    # One explicit stream for the kernel AND everything that consumes its output (the RCCL gather,
+    # the host copy of the gloo rehearsal, the strip assembly): torch.distributed orders collectives
+    # after the work already queued on torch's current stream, so the step runs with this stream
+    # current.  (torch's default stream has the handle 0, which the C ABI reads as "use the context's
+    # own stream" - a collective issued from the default stream would not wait for the kernel.)
+    side = torch.cuda.Stream(device=device)
+    stream = side.cuda_stream
+    assert stream != 0
     nown = nstrips * qd.STRIP_ROWS
     full = None
 
     def step():
+        with torch.cuda.stream(side):
+            _step()
+
+    def _step():
         nonlocal full
         if nstrips:
             ctx.render_strips_device((0, 0, W, H), rank, world, args.spp, rgb[:nown], depth[:nown], ns[:nown],

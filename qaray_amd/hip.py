@@ -161,7 +161,10 @@ class Context:
 
     def render_region_device(self, region, spp, rgb, depth, ns, max_bounce=5, seed=DEFAULT_SEED, spp_max=None,
                              stats=False, stream=None):
-        """Asynchronous render into torch CUDA tensors (float32 [h,w,3], float32 [h,w], int32/uint32 [h,w])."""
+        """Asynchronous render into torch CUDA tensors (float32 [h,w,3], float32 [h,w], int32/uint32 [h,w]).
+        stream: a HIP stream handle (e.g. torch.cuda.Stream().cuda_stream).  None or 0 - which is also the
+        handle of torch's DEFAULT stream - means the context's own non-blocking stream: call synchronize()
+        before anything else consumes the outputs, or pass a real stream and keep the consumers on it."""
         x0, y0, x1, y1 = region
         n = (x1 - x0) * (y1 - y0)
         assert rgb.is_cuda and rgb.is_contiguous() and rgb.numel() == 3 * n and rgb.element_size() == 4
