@@ -62,5 +62,11 @@ def golden_blob(meta):
     return load_scene_blob(meta["scene"], size=(meta["width"], meta["height"]))
 
 
+def reference_input_names():
+    """The reference's 28 inputs/*.xml, kept unchanged under scenes/ (SURVEY.md 8 f1)."""
+    d = os.path.join(ROOT, "scenes")
+    return sorted(f for f in os.listdir(d) if f.endswith(".xml") and (f.startswith("example_") or f.startswith("trc_")))
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)

@@ -6,13 +6,13 @@ Tolerances (fp32 radiance, written here as the contract asks):
   * radiance: scenes whose paths have at most one bounce after the camera hit and no lights
     (Cornell box = BASELINE config[1]) are bit-identical to the reference.  Elsewhere the kernel sums
     the reference's recursive radiance formula front-to-back (a throughput product instead of nested
-    multiplications) and uses fp64-rounded powf/expf instead of glibc's, which moves results by a
-    few ulp: per-image RMSE <= 1e-6 and max abs error <= 1e-4 (north_star: RMSE < 1e-4).
+    multiplications), which moves results by a few ulp: per-image RMSE <= 1e-6 and max abs error
+    <= 1e-4 (north_star: RMSE < 1e-4).  sinf/cosf/expf/powf return glibc's bits (tests/test_device_math.py).
 """
 import numpy as np
 import pytest
 
-from conftest import bits, golden_blob, load_golden
+from conftest import bits, ensure_assets, golden_blob, load_golden, reference_input_names
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,30 @@ def test_hip_matches_reference_goldens(ctx, name):
     else:
         assert rmse(g_rgb, rgb) <= RMSE_TOL
         assert float(np.abs(g_rgb - rgb).max()) <= MAXABS_TOL
+
+
+@pytest.mark.parametrize("name", reference_input_names())
+def test_every_reference_input_hip_vs_oracle(ctx, name):
+    """All 28 inputs/*.xml of the reference: none is refused, sample counts, first-hit
+    depth and cast counters are exact, radiance within the module's tolerances (scaled by the frame's largest
+    value where that exceeds 1).  The oracle is
+    pinned to the live reference on the same 28 files by tests/test_oracle_vs_reference.py."""
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 40, 30, 2
+    blob = load_scene_blob(name, size=(w, h))
+    ctx.upload_scene(blob)
+    ctx.reset_counters()
+    rgb, depth, ns = ctx.render_region((0, 0, w, h), spp)
+    cnt = ctx.counters()
+    o_rgb, o_depth, o_ns, o_cnt = oracle.render(blob, (0, 0, w, h), spp)
+    assert np.array_equal(ns, o_ns) and np.array_equal(bits(depth), bits(o_depth))
+    assert (cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]) == (o_cnt.samples, o_cnt.casts_normal, o_cnt.casts_shadow)
+    assert np.isfinite(rgb).all() == np.isfinite(o_rgb).all()
+    scale = max(1.0, float(np.abs(o_rgb[np.isfinite(o_rgb)]).max()) if np.isfinite(o_rgb).any() else 1.0)
+    assert float(np.nanmax(np.abs(rgb - o_rgb))) <= MAXABS_TOL * scale
+    assert rmse(np.nan_to_num(rgb), np.nan_to_num(o_rgb)) <= RMSE_TOL * scale
 
 
 def test_hip_matches_oracle_with_traversal_counters(ctx):
