@@ -331,7 +331,10 @@ static int PrepareScene(qa_ctx *c)
   // Without reflective / refractive lobes a path is at most camera ray + one diffuse bounce: starting
   // the samples of a wave together keeps its coherent camera rays apart from the incoherent bounce
   // rays (+21 % on the Cornell box).  Long specular chains would make lanes wait for the longest path.
-  c->syncAuto = anySpecularLobes ? 0 : 1;
+  // Textured scenes also start samples together: the 32-tap filtered lookups of camera hits are the
+  // expensive part of their shading and stay coherent that way (+18 % on project7_object, whereas the
+  // untextured glossy-caustics scene loses 14 % to waiting for its long specular chains).
+  c->syncAuto = (!anySpecularLobes || textured) ? 1 : 0;
   if (area) {
     // hit log of the AREA variants: QA_MAX_PATH x 19 floats per thread of the largest grid
     const size_t threads = (size_t) c->numCUs * 8 * QA_BLOCK;
