@@ -103,6 +103,7 @@ class Context:
         _check(lib().qa_ctx_create(int(device_id), C.byref(self._h)))
         self.device_id = int(device_id)
         self.size = None
+        self._photon_sizes = None
 
     # -- scene ---------------------------------------------------------------------------------
     def upload_scene(self, blob):
@@ -110,6 +111,7 @@ class Context:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         _check(lib().qa_scene_upload(self._h, blob.ctypes.data, blob.size))
         self._remember_size(blob)
+        self._photon_sizes = None   # a new scene drops the photon maps
 
     def upload_scene_device(self, dev_tensor):
         """dev_tensor: torch uint8 CUDA tensor holding a flat scene (e.g. after a broadcast)."""
@@ -132,6 +134,7 @@ class Context:
 
     def clear_photon_maps(self):
         _check(lib().qa_photon_maps_clear(self._h))
+        self._photon_sizes = None
 
     def photon_maps_info(self):
         """-> (emitted[2], emissions[2]): numOfEmittedRays and emission-loop iterations per map."""
@@ -141,6 +144,8 @@ class Context:
 
     def download_photon_map(self, which):
         """-> the balanced qa_photon records as they sit in HBM, size + 1 entries ([0] unused)."""
+        if self._photon_sizes is None:
+            raise HipError(-5, "no photon maps built")
         out = np.zeros(self._photon_sizes[which] + 1, PHOTON_DTYPE)
         _check(lib().qa_photon_maps_download(self._h, which, out.ctypes.data, out.size))
         return out
