@@ -129,11 +129,18 @@ __device__ __forceinline__ void photonEstimate(const DPhotonMap &pm, f3 pos, f3 
   }
 }
 
-// the gather term of Shade (MtlBlinn_PhotonMap.cpp:426-458).  A real call, not inlined: the kd-tree
-// walk and the heap need ~60 registers of their own, which would otherwise be taken from the
-// integrator loop around it on every iteration, not only at the hits that gather.
-__device__ __attribute__((noinline)) f3 photonGather(const DPhotonMap &pm, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, uint32_t *stack,
-                                                     uint2 *heap, size_t stride)
+// the gather term of Shade (MtlBlinn_PhotonMap.cpp:426-458).  Inlined by default (20 % faster than a
+// call); -DQA_PM_CALL keeps it a real call, which was the remedy while an earlier version of the
+// walk - one that indexed a private float[3] with the split axis - returned different pixels from
+// run to run when inlined at 128 VGPRs.  tests/test_gpu_photon.py renders every
+// photon frame three times and requires identical bits.
+#ifdef QA_PM_CALL
+#define QA_PM_GATHER_ATTR __attribute__((noinline))
+#else
+#define QA_PM_GATHER_ATTR __forceinline__
+#endif
+__device__ QA_PM_GATHER_ATTR f3 photonGather(const DPhotonMap &pm, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, uint32_t *stack,
+                                             uint2 *heap, size_t stride)
 {
   f3 I, D;
   photonEstimate(pm, p, N, stack, heap, stride, I, D);
