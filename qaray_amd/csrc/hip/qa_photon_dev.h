@@ -27,14 +27,14 @@ __device__ __forceinline__ void photonPack(f3 power, f3 dir, float &maxPower, ui
 // PhotonMap::LocatePhotons + EstimateIrradiance<100> with a normal, ellipticity 1 and the quadratic
 // filter.  The reference recurses (far child, near child, then the node itself) and keeps copies of
 // the found photons; here the recursion is an explicit stack of (node, phase) words in the lane's
-// LDS traversal stack, and the heap keeps photon indices: the lane's column of a global scratch
-// slab, one 8-byte (distance, index) element per slot.  Directions and powers come decoded from the tables
+// LDS traversal stack, and the heap keeps photon indices: the lane's 101 consecutive 8-byte
+// (distance, index) elements of a global scratch slab.  Directions and powers come decoded from the tables
 // of DPhotonMap (same values as Photon::GetDirection / GetPower return).
-__device__ __forceinline__ void photonEstimate(const DPhotonMap &pm, f3 pos, f3 N, uint32_t *stack, uint2 *heap, size_t stride,
-                                               f3 &irrad, f3 &direction)
+__device__ __forceinline__ void photonEstimate(const DPhotonMap &pm, f3 pos, f3 N, uint32_t *stack, uint2 *heap, f3 &irrad,
+                                               f3 &direction)
 {
-  // heap element k of this lane: (distance^2 bits, photon index) at heap[k * stride]
-  auto H = [&](int k) -> uint2 & { return heap[(size_t) k * stride]; };
+  // heap element k of this lane: (distance^2 bits, photon index)
+  auto H = [&](int k) -> uint2 & { return heap[k]; };
   irrad = F3(0, 0, 0);
   direction = F3(0, 0, 0);
   float d2max = pm.radius * pm.radius;  // np.dist2[0]
@@ -140,10 +140,10 @@ __device__ __forceinline__ void photonEstimate(const DPhotonMap &pm, f3 pos, f3 
 #define QA_PM_GATHER_ATTR __forceinline__
 #endif
 __device__ QA_PM_GATHER_ATTR f3 photonGather(const DPhotonMap &pm, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, uint32_t *stack,
-                                             uint2 *heap, size_t stride)
+                                             uint2 *heap)
 {
   f3 I, D;
-  photonEstimate(pm, p, N, stack, heap, stride, I, D);
+  photonEstimate(pm, p, N, stack, heap, I, D);
   if (luma(I) > 0.00001f) {
     const f3 L = -normalize(D);
     const f3 H = normalize(V + L);

@@ -153,7 +153,7 @@ struct RenderParams {
   const volatile int *stop_flag;
   DCounters *counters;
   // PHOTON kernel variants (Scene::usePhotonMap): [0] photon map, [1] caustics map, and the per-lane
-  // nearest-photon heaps ([QA_PHOTON_GATHER + 1][grid threads] x (distance^2, photon index))
+  // nearest-photon heaps ([grid threads][QA_PHOTON_GATHER + 1] x (distance^2, photon index))
   DPhotonMap pm[2];
   uint2 *heap;
 };
