@@ -67,8 +67,12 @@ int qa_scene_upload_device(qa_ctx *ctx, const void *device_blob, uint64_t nbytes
  * depth: hit distance of sample 0 (1e30 on a miss), nsamples: samples taken (0 = pixel skipped
  * because a stop was requested).  Pixel (i,j) always uses RNG stream qa_pixel_seed(seed,
  * j*width+i) (include/qa_seed.h), so any partition of the image gives identical pixels.
+ * 1 <= spp_min <= spp_max: spp_min samples always, up to spp_max while the running variance
+ * exceeds the reference's thresholds (SuperSamplerHalton::Loop, src/scene/scene.cpp:92-97).
  * The host variant synchronises and copies back; the device variant writes device buffers and
- * only enqueues work on `hip_stream` (a hipStream_t, NULL = the context's own stream). */
+ * only enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream -
+ * note that NULL is also the handle of the legacy default stream, which therefore cannot be
+ * selected: consumers on other streams must wait for qa_synchronize or pass their own stream). */
 int qa_render_region(qa_ctx *ctx, int x0, int y0, int x1, int y1, int spp_min, int spp_max,
                      int max_bounce, uint32_t seed, uint32_t flags, float *rgb, float *depth,
                      uint32_t *nsamples);

@@ -421,7 +421,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (!c->haveScene) return Fail(QA_ENOSCENE, "no scene uploaded");
   if (x0 < 0 || y0 < 0 || x1 > c->ds.cam.width || y1 > c->ds.cam.height || x1 <= x0 || y1 <= y0)
     return Fail(QA_EINVAL, "region outside the image");
-  if (spp_min < 0 || spp_max < spp_min || spp_max < 1 || max_bounce < 0) return Fail(QA_EINVAL, "bad spp / bounce");
+  // sppMin = 0 would mean "no sample at all" (SuperSamplerHalton::Loop, src/scene/scene.cpp:92-97): refused
+  if (spp_min < 1 || spp_max < spp_min || max_bounce < 0) return Fail(QA_EINVAL, "bad spp / bounce");
   if (c->area && max_bounce + 1 > QA_MAX_PATH) return Fail(QA_EUNSUPPORTED, "area lights: maxBounce must be <= 7");
   if (!d_rgb || !d_depth || !d_ns) return Fail(QA_EINVAL, "null output buffer");
   int rc = EnsureHalton(c, spp_max);
