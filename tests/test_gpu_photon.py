@@ -93,6 +93,29 @@ def test_default_sized_maps_against_oracle(ctx):
         ctx.photon_maps_info()
 
 
+@pytest.mark.parametrize("scene,pm,cm", [("trc_scene_xmas.xml", (3000, 20, 0.5), (300, 20, 1.0)),     # area + spot lights, 40 nodes
+                                         ("trc_scene_tower.xml", (2000, 20, 1.0), (100, 20, 2.0))])   # 361 k triangles in global memory
+def test_photon_maps_on_large_scenes_against_oracle(ctx, scene, pm, cm):
+    from conftest import ensure_assets
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 64, 48, 2
+    blob = load_scene_blob(scene, size=(w, h))
+    pp = oracle.photon_params(pm, cm)
+    o_pm, o_cm, o_emitted, o_emissions = oracle.photon_build(blob, pp)
+    ctx.upload_scene(blob)
+    ctx.build_photon_maps(pm, cm)
+    assert ctx.photon_maps_info() == (o_emitted, o_emissions)
+    assert ctx.download_photon_map(0).tobytes() == o_pm.tobytes()
+    assert ctx.download_photon_map(1).tobytes() == o_cm.tobytes()
+    rgb, depth, ns = ctx.render_region((0, 0, w, h), spp)
+    o_rgb, o_depth, o_ns, _ = oracle.render(blob, (0, 0, w, h), spp, photon=(pp, o_pm, o_cm))
+    assert np.array_equal(bits(depth), bits(o_depth)) and np.array_equal(ns, o_ns)
+    assert float(np.abs(rgb - o_rgb).max()) <= REL_MAX_TOL * max(1.0, float(np.abs(o_rgb).max()))
+    ctx.clear_photon_maps()
+
+
 def test_strips_with_photon_maps_equal_full_frame(ctx):
     """The multi-GPU partition (round-robin 8-row strips) with maps built independently per 'rank'."""
     import torch
