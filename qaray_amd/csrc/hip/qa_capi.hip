@@ -12,6 +12,7 @@
 
 #include "qa_kernel_sm.h"
 #include "qa_ctx.h"
+#include "qa_fastbvh.h"
 
 // core/sampler.cpp:31-40, evaluated on the host in the reference's fp32 order
 static float HaltonF(int index, int base)
@@ -151,6 +152,10 @@ static int PrepareScene(qa_ctx *c)
   std::vector<std::vector<DNode>> allNodes(h->num_meshes);
   std::vector<std::vector<DTri>> allTris(h->num_meshes);
   std::vector<std::vector<DTriShade>> allShade(h->num_meshes);
+  std::vector<std::vector<DNode>> allFNodes(h->num_meshes);     // the library's own trees (qa_fastbvh.h)
+  std::vector<std::vector<DTri>> allFTris(h->num_meshes);
+  std::vector<std::vector<uint32_t>> allFMap(h->num_meshes);
+  std::vector<std::pair<double, double>> fastCost(h->num_meshes, {0.0, 0.0});   // expected ray cost: reference tree, own tree
   uint32_t stackNeedMax = 1;
   for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
     const qa_mesh &m = mesh[mi];
@@ -235,6 +240,48 @@ static int PrepareScene(qa_ctx *c)
       s.face = fid;
       s.pad = 0;
     }
+    // ---- what the non-counting kernels need to search their own tree and to validate the answer
+    // against the reference's (qa_kernel.h hitMesh): element -> leaf links of the reference tree, and the
+    // SAH tree over the same triangles
+    for (uint32_t i = 1; i < m.num_bvh_nodes; ++i) {
+      if (nodes[i].data & QA_BVH_LEAF_BIT) {
+        const uint32_t cnt = ((nodes[i].data >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1, off = nodes[i].data & QA_BVH_OFFSET_MASK;
+        for (uint32_t q = 0; q < cnt; ++q) dsh[off + q].pad = i;
+      }
+    }
+    {
+      std::vector<float> bounds(6 * (size_t) m.num_faces);
+      for (uint32_t e = 0; e < m.num_faces; ++e) {
+        const qa_face &f = faces[elements[e]];
+        float *bb = &bounds[6 * (size_t) e];
+        for (int k = 0; k < 3; ++k) { bb[k] = 1e30f; bb[3 + k] = -1e30f; }
+        for (int v = 0; v < 3; ++v)
+          for (int k = 0; k < 3; ++k) {
+            const float x = V[3 * (size_t) f.v[v] + k];
+            if (x < bb[k]) bb[k] = x;
+            if (x > bb[3 + k]) bb[3 + k] = x;
+          }
+      }
+      FastBvh fb;
+      const unsigned leafMax = getenv("QA_FAST_LEAF") ? (unsigned) atoi(getenv("QA_FAST_LEAF")) : 2u;
+      try { FastBvhBuilder(bounds.data(), m.num_faces, leafMax).Run(fb); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+      if (fb.nodes.size() & 1) fb.nodes.push_back(DNode{});
+      {
+        float rootBox[6];
+        memcpy(rootBox, m.bmin, 12);
+        memcpy(rootBox + 3, m.bmax, 12);
+        const double costRef = m.num_bvh_nodes > 1 ? TreeCost(dn.data(), nodes[1].data, rootBox) : 0;
+        const double costFast = TreeCost(fb.nodes.data(), fb.rootData, rootBox);
+        fastCost[mi] = {costRef, costFast};
+        if (getenv("QA_FAST_VERBOSE")) fprintf(stderr, "mesh %u: %u triangles, expected ray cost reference tree %.2f, own tree %.2f (depth %u)\n", mi, m.num_faces, costRef, costFast, fb.depth);
+      }
+      allFNodes[mi] = fb.nodes;
+      allFMap[mi] = fb.order;
+      allFTris[mi].resize(m.num_faces);
+      for (uint32_t i = 0; i < m.num_faces; ++i) allFTris[mi][i] = dt[fb.order[i]];
+      if (fb.depth > stackNeed) stackNeed = fb.depth;
+      if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
+    }
     // texture vertices per triangle (element order); a mesh must have them on every face or none
     const float *VT = QA_BLOB_PTR(float, blob, m.off_texcoords);
     std::vector<float> vts;
@@ -267,11 +314,25 @@ static int PrepareScene(qa_ctx *c)
     dm.num_faces = m.num_faces;
     dm.num_nodes = m.num_bvh_nodes;
     dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
+    dm.frootData = (m.num_faces && allFNodes[mi].size() > 1) ? allFNodes[mi][1].data : QA_DONE;
+    dm.useFast = (m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
+    // refReaches tests a leaf's box only: valid when every inner box contains its children's boxes
+    // (true for cy::BVH, whose inner boxes are unions); a blob that breaks this keeps the reference tree
+    for (uint32_t i = 1; i < m.num_bvh_nodes && dm.useFast; ++i) {
+      if (nodes[i].data & QA_BVH_LEAF_BIT) continue;
+      const uint32_t ch = nodes[i].data & QA_BVH_CHILD_MASK;
+      for (uint32_t q = ch; q < ch + 2; ++q)
+        for (int k = 0; k < 3; ++k)
+          if (!(nodes[q].box[k] >= nodes[i].box[k] && nodes[q].box[k + 3] <= nodes[i].box[k + 3])) dm.useFast = 0;
+    }
     dm.stackNeed = stackNeed;
     int rc;
     if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, dt, &dm.tris)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, dsh, &dm.shade)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, allFNodes[mi], &dm.fnodes)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, allFTris[mi], &dm.ftris)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, allFMap[mi], &dm.fmap)) != QA_OK) return rc;
   }
 
   // ---- material table (plain colours) -----------------------------------------------------------
@@ -309,6 +370,10 @@ static int PrepareScene(qa_ctx *c)
     dmeshes[mi].resNodes = append(allNodes[mi].data(), allNodes[mi].size() * sizeof(DNode));
     dmeshes[mi].resTris = append(allTris[mi].data(), allTris[mi].size() * sizeof(DTri));
     dmeshes[mi].resShade = append(allShade[mi].data(), allShade[mi].size() * sizeof(DTriShade));
+    while (image.size() % 4) image.push_back(uint4{0, 0, 0, 0});
+    dmeshes[mi].resFNodes = append(allFNodes[mi].data(), allFNodes[mi].size() * sizeof(DNode));
+    dmeshes[mi].resFTris = append(allFTris[mi].data(), allFTris[mi].size() * sizeof(DTri));
+    dmeshes[mi].resFMap = append(allFMap[mi].data(), allFMap[mi].size() * sizeof(uint32_t));
   }
   const uint32_t resMaterials = append(dmat.data(), dmat.size() * sizeof(DMaterial));
 

@@ -360,6 +360,35 @@ __device__ __forceinline__ bool hitTriangleZ(const uint4 q0, const uint4 q1, con
   if (ok) hz = t;
   return ok;
 }
+// The same test on the library's own tree: the accept rule is unchanged, and `tie` is raised when a
+// triangle passes everything but arrives at exactly the distance already held - the one situation
+// in which the order of the tests decides who wins (hitMesh then repeats the query in the
+// reference's order).
+__device__ __forceinline__ bool hitTriangleZTie(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, float &hz, bool &tie)
+{
+  const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
+  const f3 A = F3(asF(q0.w), asF(q1.x), asF(q1.y));
+  const float dz = dot(ray.d, N);
+  const float pz = dot(ray.p - A, N);
+  const float t = -pz / dz;
+  const bool pre = !(qabs(dz) < 1e-7f) && !(t <= QA_BIAS);
+  const uint32_t axis = q2.w;
+  const f3 p = ray.p + ray.d * t;
+  const bool ax0 = (axis == 0), ax2 = (axis == 2);
+  const float pu = ax0 ? p.y : p.x;
+  const float pv = ax2 ? p.y : p.z;
+  const float au = ax0 ? A.y : A.x;
+  const float av = ax2 ? A.y : A.z;
+  const float bu = asF(q1.z), bv = asF(q1.w), cu = asF(q2.x), cv = asF(q2.y), s = asF(q2.z);
+  const float a = ((bu - pu) * (cv - pv) - (cu - pu) * (bv - pv)) * s;
+  const float b = ((cu - pu) * (av - pv) - (au - pu) * (cv - pv)) * s;
+  const float c = 1.f - a - b;
+  const bool inside = pre && !(a < 0 || b < 0 || c < 0);
+  const bool ok = inside && (hz > t);
+  tie = tie || (inside && hz == t);
+  if (ok) hz = t;
+  return ok;
+}
 __device__ __forceinline__ void triangleDetails(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, Hit &h,
                                                 float &ba, float &bb)
 {
@@ -387,27 +416,20 @@ __device__ __forceinline__ void triangleDetails(const uint4 q0, const uint4 q1, 
 // read of the sibling pair.
 struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element order) and its barycentrics
 
-template <bool RES, bool STATS>
-__device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
-                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt,
-                                        TriPick &pick)
+// One BVH walk.  FAST = false: the reference's tree and rules - near child first, far child stacked,
+// strict tests (entry < t_max, entry < exit), a leaf's triangles in element order, first accepted
+// wins at equal distance (objects.cpp:342-419).  FAST = true: the library's own tree (qa_fastbvh.h)
+// with non-strict box tests, and `tie` is raised when a triangle passes the inside test at exactly
+// the distance already held.  Returns whether a triangle was accepted; best = its element index in
+// the walked tree's order.  closest = false stops at the first accepted triangle.
+template <bool FAST, bool STATS>
+__device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, uint32_t rootData, const Ray &ray, f3 drcp,
+                                        bool fastSlab, float &hz, bool closest, uint32_t *stack, DCounters &cnt,
+                                        uint32_t &best, bool &tie)
 {
-  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-  {
-    float entry, exit_;
-    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, exit_);
-    if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
-  }
-  if (m.num_faces == 0) return false;
-  // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
-  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
-  const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
-  const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
   bool hasHit = false;
   int sp = 0;
-  uint32_t bestTri = 0;
-  float ba = 0, bb = 0;
-  uint32_t cur = m.rootData;
+  uint32_t cur = rootData;
   while (cur != QA_DONE) {
     // ---- descend inner nodes until this lane holds a leaf (or runs out of work) --------------
     while (!(cur & QA_BVH_LEAF_BIT)) {
@@ -424,9 +446,9 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
         boxEntryExit(ray, drcp, min0, max0, entry0, exit0);
         boxEntryExit(ray, drcp, min1, max1, entry1, exit1);
       }
-      const float t_max = h.z;
-      const bool hit0 = (entry0 < t_max && entry0 < exit0);
-      const bool hit1 = (entry1 < t_max && entry1 < exit1);
+      const float t_max = hz;
+      const bool hit0 = FAST ? (entry0 <= t_max && entry0 <= exit0) : (entry0 < t_max && entry0 < exit0);
+      const bool hit1 = FAST ? (entry1 <= t_max && entry1 <= exit1) : (entry1 < t_max && entry1 < exit1);
       const uint32_t d0 = a1.z, d1 = b1.z;
       if (hit0 && hit1) {
         // the reference pushes the far child, then the near one, and pops the near one next
@@ -445,21 +467,106 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     for (uint32_t i = 0; i < count; ++i) {
       if (STATS) cnt.tri_tests++;
       const uint4 *t = tris + 3 * (size_t) (first + i);
-      if (hitTriangleZ(t[0], t[1], t[2], ray, h.z)) {
+      bool accepted;
+      if constexpr (FAST) accepted = hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie);
+      else accepted = hitTriangleZ(t[0], t[1], t[2], ray, hz);
+      if (accepted) {
         hasHit = true;
-        bestTri = first + i;
+        best = first + i;
         if (!closest) return true;
       }
     }
     cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
   }
-  if (hasHit && closest) {
+  return hasHit;
+}
+
+// Would the reference's walk have reached the leaf `leaf` of its tree?  It enters a node when the
+// strict box test passes against the distance held at that moment.  Every inner box of the tree is
+// the union of its children's boxes (min / max of the same floats), and the slab arithmetic is
+// monotone in the box bounds, so an ancestor's [entry, exit] interval contains the leaf's: if the
+// LEAF's box passes the strict test against `limit`, every node above it does.  `limit` is the final
+// hit distance for a closest-hit query (the distance held earlier can only be larger: sufficient),
+// the fixed t_max for an any-hit query (exact).  DTriShade::pad holds an element's leaf id.
+__device__ __forceinline__ bool refReaches(const uint4 *nodes, uint32_t leaf, const Ray &ray, f3 drcp, bool fastSlab, float limit)
+{
+  if (leaf <= 1) return true;   // the root is entered unconditionally (the mesh bounds were tested by the caller)
+  const uint4 n0 = nodes[2 * (size_t) leaf], n1 = nodes[2 * (size_t) leaf + 1];
+  float entry, exit_;
+  const f3 bmin = F3(asF(n0.x), asF(n0.y), asF(n0.z)), bmax = F3(asF(n0.w), asF(n1.x), asF(n1.y));
+  if (fastSlab) boxEntryExitFast(ray, drcp, bmin, bmax, entry, exit_);
+  else boxEntryExit(ray, drcp, bmin, bmax, entry, exit_);
+  return entry < limit && entry < exit_;
+}
+
+// TriObj::IntersectRay + TraceBVHNode (src/objects/objects.cpp:310-420).
+//
+// The closest hit of a mesh does not depend on the tree it is searched with - except where the
+// reference's own search is not exhaustive: it enters a child box only on strict inequalities (a
+// flat box is never entered), and at equal distance it keeps the triangle it met first.  Counting
+// kernels (STATS) therefore walk the reference's tree exactly as the reference does.  The others
+// walk the library's SAH tree (qa_fastbvh.h: two triangles per leaf, padded boxes, non-strict
+// tests, so that it reaches every triangle the reference can reach; 2.7 instead of 15 triangle
+// tests per cast on the Cornell box) and then check the answer against the reference's rules:
+// the found triangle must be reachable in the reference's tree (refReaches) and no tie may have
+// been seen; otherwise the lane repeats the query on the reference's tree.
+template <bool RES, bool STATS>
+__device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
+                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt,
+                                        TriPick &pick)
+{
+  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  {
+    float entry, exit_;
+    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, exit_);
+    if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
+  }
+  if (m.num_faces == 0) return false;
+  // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
+  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
+  const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
+  const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
+  const uint4 *shade = RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade);
+  bool hasHit = false;
+  uint32_t bestTri = 0;
+  bool tie = false;
+  // Global-memory scenes keep the reference tree: there every inner step is a dependent memory round
+  // trip, and the SAH tree's longer chains of small nodes cost more than its fewer triangle tests save
+  // (measured: tower scene 182 -> 199 ms, glossy caustics 52 -> 61 ms, project7_object 99 -> 93 ms),
+  // while carrying both walks in one kernel costs those scenes 5 - 10 % in registers alone.
+  if constexpr (STATS || !RES) {
+    hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+  } else if (!m.useFast) {
+    hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+  } else {
+    const uint4 *fnodes = RES ? mem.img + m.resFNodes : reinterpret_cast<const uint4 *>(m.fnodes);
+    const uint4 *ftris = RES ? mem.img + m.resFTris : reinterpret_cast<const uint4 *>(m.ftris);
+    const uint32_t *fmap = RES ? reinterpret_cast<const uint32_t *>(mem.img + m.resFMap) : m.fmap;
+    const float hz0 = h.z;
+    uint32_t bestF = 0;
+    hasHit = walkBVH<true, false>(fnodes, ftris, m.frootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestF, tie);
+    bool redo = tie;
+    if (hasHit) {
+      bestTri = fmap[bestF];
+      const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad
+      // closest: the distance just found; any-hit: the fixed t_max (h.z is untouched by walkBVH then... it is
+      // set to the accepted distance, so take the saved one)
+      redo = redo || !refReaches(nodes, leaf, ray, drcp, fastSlab, closest ? h.z : hz0);
+    }
+    if (redo) {
+      h.z = hz0;
+      hasHit = walkBVH<false, false>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+    }
+  }
+  if (!closest) return hasHit;
+  if (hasHit) {
+    float ba = 0, bb = 0;
     {
       const uint4 *t = tris + 3 * (size_t) bestTri;
       triangleDetails(t[0], t[1], t[2], ray, h, ba, bb);
     }
     // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
-    const uint4 *s = (RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade)) + 3 * (size_t) bestTri;
+    const uint4 *s = shade + 3 * (size_t) bestTri;
     const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
     const float bc = 1.f - ba - bb;
     const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)),

@@ -46,7 +46,7 @@ struct alignas(16) DTriShade {
   float n0[3], n1[3], n2[3];   // vertex normals (TriMesh::GetNormal interpolates them)
   int32_t mtl;
   uint32_t face;               // original face id (texture coordinates are looked up by it)
-  uint32_t pad;
+  uint32_t pad;                // id of the reference-tree leaf that holds this element; see refReaches
 };
 static_assert(sizeof(DTriShade) == 48, "DTriShade must be 3 x 16 bytes");
 
@@ -76,6 +76,13 @@ struct DMesh {
   uint32_t resNodes, resTris, resShade;
   uint32_t hasVT;              // every face carries texture vertices (mixed meshes are refused)
   const float *vt;             // [6 * num_faces] texture vertices per triangle, element order
+  // the library's own search tree over the same triangles (qa_fastbvh.h); non-counting kernels walk it
+  const DNode *fnodes;         // same node format and numbering rules as `nodes`
+  const DTri *ftris;           // the records of `tris`, in this tree's leaf order
+  const uint32_t *fmap;        // element of this tree -> element of the reference tree
+  uint32_t frootData;
+  uint32_t useFast;            // 0: this mesh is searched with the reference tree only
+  uint32_t resFNodes, resFTris, resFMap;
 };
 
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
