@@ -96,6 +96,27 @@ def test_hip_matches_oracle_with_traversal_counters(ctx):
     assert cnt["pixels"] == 160 * 90
 
 
+@pytest.mark.parametrize("scene,size,spp", [("example_project12_box.xml", (960, 540), 32), ("custom_textures.xml", (480, 360), 8),
+                                            ("custom_photon.xml", (320, 240), 4)])
+def test_own_search_tree_equals_reference_tree_walk(ctx, scene, size, spp):
+    """LDS-resident scenes: the default kernels search meshes with the library's SAH tree and validate
+    the hit against the reference tree's rules (qa_kernel.h hitMesh); the counting kernels walk the
+    reference's cy::BVH exactly as the reference does.  Both must return the same bits - here on
+    10^7..10^8 casts per scene, far more than the goldens hold."""
+    from qaray_amd.host import load_scene_blob
+    w, h = size
+    ctx.upload_scene(load_scene_blob(scene, size=size))
+    ctx.reset_counters()
+    a = ctx.render_region((0, 0, w, h), spp)
+    ca = ctx.counters()
+    ctx.reset_counters()
+    b = ctx.render_region((0, 0, w, h), spp, stats=True)
+    cb = ctx.counters()
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    assert (ca["samples"], ca["casts_normal"], ca["casts_shadow"]) == (cb["samples"], cb["casts_normal"], cb["casts_shadow"])
+    assert cb["tri_tests"] > 0 and ca["tri_tests"] == 0
+
+
 def test_partition_invariance_and_determinism_full_size(ctx):
     """Properties at BASELINE's full frame size (1920x1080): a region rendered alone, as part of a
     bigger region, or as round-robin strips gives the same bits; two runs give the same bits."""
