@@ -16,6 +16,7 @@
 #include "qa_photon.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #ifdef _OPENMP
@@ -462,10 +463,21 @@ static inline v3 tri_texcoord(const meshview_t *mv, const qa_face *f, v3 bc)
 }
 
 /* src/objects/objects.cpp:212-306 */
+/* debugging aid: QA_ORACLE_TRACE="i,j,sample" prints the casts of that sample (rays, triangle tests) to stderr */
+static int g_trace_on = 0;
+static int g_trace_px = -1, g_trace_py = -1, g_trace_s = -1;
+
 static int triangle_intersect(const meshview_t *mv, const ray_t *ray, hit_t *hc, uint32_t faceID,
                               const diffray_t *dr, diffhit_t *dh, tls_t *tl)
 {
   tl->cnt.tri_tests++;
+  if (g_trace_on) {
+    const qa_face *f_ = &mv->faces[faceID];
+    const v3 A_ = v3p(mv->V + 3 * f_->v[0]), B_ = v3p(mv->V + 3 * f_->v[1]), C_ = v3p(mv->V + 3 * f_->v[2]);
+    const v3 N_ = vnormalize(vcross(vsub(B_, A_), vsub(C_, A_)));
+    const float dz_ = vdot(ray->dir, N_), pz_ = vdot(vsub(ray->p, A_), N_);
+    fprintf(stderr, "    tri face %u: t %a (%.9g) held %a dz %g\n", faceID, -pz_ / dz_, -pz_ / dz_, hc->z, dz_);
+  }
   const qa_face *f = &mv->faces[faceID];
   const v3 A = v3p(mv->V + 3 * f->v[0]);
   const v3 B = v3p(mv->V + 3 * f->v[1]);
@@ -490,6 +502,7 @@ static int triangle_intersect(const meshview_t *mv, const ray_t *ray, hit_t *hc,
     const float c = 1.f - a - b;
     if (a < 0 || b < 0 || c < 0) return 0;
     const v3 bc = V3(a, b, c);
+    if (g_trace_on) fprintf(stderr, "      ACCEPT face %u t %a bary %g %g %g\n", faceID, t, a, b, c);
     hc->z = t;
     if (dr != NULL && dh != NULL) {
       const int hasVT = (f->vt[0] >= 0) && (f->vt[1] >= 0) && (f->vt[2] >= 0);
@@ -674,6 +687,7 @@ static int trace_normal_node(const scene_t *s, int k, const diffray_t *ray, diff
 static int trace_normal(const scene_t *s, const diffray_t *ray, diffhit_t *h, tls_t *tl)
 {
   tl->cnt.casts_normal++;
+  if (g_trace_on) fprintf(stderr, "  cast p %a %a %a  d %a %a %a\n", ray->c.p.x, ray->c.p.y, ray->c.p.z, ray->c.dir.x, ray->c.dir.y, ray->c.dir.z);
   return trace_normal_node(s, 0, ray, h, tl);
 }
 
@@ -1417,6 +1431,8 @@ static void render_pixel(const scene_t *s, int i, int j, int spp_min, int spp_ma
       const v3 ds = V3(r * cosf(t), r * sinf(t), 0.f);
       campos = vadd(campos, vadd(vscale(v3p(h->screenX), ds.x), vscale(v3p(h->screenY), ds.y)));
     }
+    g_trace_on = (i == g_trace_px && j == g_trace_py && sidx == g_trace_s);
+    if (g_trace_on) fprintf(stderr, "pixel %d %d sample %d\n", i, j, sidx);
     diffray_t ray;
     ray.c.p = campos; ray.c.dir = vnormalize(vsub(cpt, campos));
     ray.x.p = campos; ray.x.dir = vnormalize(vsub(xpt, campos));
@@ -1444,6 +1460,7 @@ static void render_pixel(const scene_t *s, int i, int j, int spp_min, int spp_ma
       else
         color_std = vadd(color_std, V3(0.0f, 0.0f, 0.0f));
     }
+    g_trace_on = 0;
     ++sidx;
     tl->cnt.samples++;
   }
@@ -1494,6 +1511,9 @@ int qa_oracle_render_pm(const void *blob, int x0, int y0, int x1, int y1, int sp
   }
   if (x0 < 0 || y0 < 0 || x1 > (int) s.h->width || y1 > (int) s.h->height || x1 < x0 || y1 < y0) return -2;
   s.max_bounce = max_bounce;
+  if (getenv("QA_ORACLE_TRACE")) {
+    if (sscanf(getenv("QA_ORACLE_TRACE"), "%d,%d,%d", &g_trace_px, &g_trace_py, &g_trace_s) == 3) threads = 1;
+  }
   const int cw = x1 - x0, ch = y1 - y0;
   qa_oracle_counters total;
   memset(&total, 0, sizeof(total));

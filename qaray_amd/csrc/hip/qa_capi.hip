@@ -156,6 +156,8 @@ static int PrepareScene(qa_ctx *c)
   std::vector<std::vector<DTri>> allFTris(h->num_meshes);
   std::vector<std::vector<uint32_t>> allFMap(h->num_meshes);
   std::vector<std::pair<double, double>> fastCost(h->num_meshes, {0.0, 0.0});   // expected ray cost: reference tree, own tree
+  std::vector<float> meshInvH(h->num_meshes, 0.f), meshAbsMax(h->num_meshes, 0.f);
+  std::vector<std::vector<float>> meshNormals(h->num_meshes);   // x, y, z, 0 per distinct face normal; empty = too many
   uint32_t stackNeedMax = 1;
   for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
     const qa_mesh &m = mesh[mi];
@@ -262,6 +264,42 @@ static int PrepareScene(qa_ctx *c)
             if (x > bb[3 + k]) bb[3 + k] = x;
           }
       }
+      // smallest altitude over all triangles: 2 * area / longest edge (degenerate triangles never pass the
+      // reference's test - their normal is NaN - and are left out)
+      double hMin = 1e300;
+      for (uint32_t e = 0; e < m.num_faces; ++e) {
+        const qa_face &f = faces[elements[e]];
+        const float *A = V + 3 * (size_t) f.v[0], *B = V + 3 * (size_t) f.v[1], *C = V + 3 * (size_t) f.v[2];
+        const double ab[3] = {(double) B[0] - A[0], (double) B[1] - A[1], (double) B[2] - A[2]};
+        const double ac[3] = {(double) C[0] - A[0], (double) C[1] - A[1], (double) C[2] - A[2]};
+        const double bc[3] = {(double) C[0] - B[0], (double) C[1] - B[1], (double) C[2] - B[2]};
+        const double cr[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+        const double area2 = std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        const double L = std::sqrt(std::max({ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2], ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2],
+                                             bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]}));
+        if (area2 > 0 && L > 0) hMin = std::min(hMin, area2 / L);
+      }
+      float absMax = 0;
+      for (int k = 0; k < 3; ++k) absMax = std::max(absMax, std::max(std::fabs(m.bmin[k]), std::fabs(m.bmax[k])));
+      // distinct face normals up to sign (the DTri records hold the reference's own normalize(cross()))
+      {
+        std::vector<float> &nl = meshNormals[mi];
+        bool overflow = false;
+        for (uint32_t e = 0; e < m.num_faces && !overflow; ++e) {
+          const float *N = dt[e].N;
+          if (!(N[0] == N[0])) continue;   // degenerate triangle: NaN normal, never accepted
+          bool seen = false;
+          for (size_t q = 0; q + 3 < nl.size() + 1 && !seen; q += 4)
+            seen = (nl[q] == N[0] && nl[q + 1] == N[1] && nl[q + 2] == N[2]) || (nl[q] == -N[0] && nl[q + 1] == -N[1] && nl[q + 2] == -N[2]);
+          if (!seen) {
+            if (nl.size() >= 4 * 24) overflow = true;
+            else { nl.push_back(N[0]); nl.push_back(N[1]); nl.push_back(N[2]); nl.push_back(0.f); }
+          }
+        }
+        if (overflow) nl.clear();
+      }
+      meshInvH[mi] = hMin < 1e300 ? (float) (1.0 / hMin) : 0.f;
+      meshAbsMax[mi] = absMax;
       FastBvh fb;
       const unsigned leafMax = getenv("QA_FAST_LEAF") ? (unsigned) atoi(getenv("QA_FAST_LEAF")) : 2u;
       try { FastBvhBuilder(bounds.data(), m.num_faces, leafMax).Run(fb); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
@@ -316,6 +354,16 @@ static int PrepareScene(qa_ctx *c)
     dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
     dm.frootData = (m.num_faces && allFNodes[mi].size() > 1) ? allFNodes[mi][1].data : QA_DONE;
     dm.useFast = (m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
+    dm.invH = meshInvH[mi];
+    dm.absMax = meshAbsMax[mi];
+    {
+      // needle-like triangles would widen the own tree's boxes (200 eps P^2 / h, see hitMesh) to a sizeable
+      // part of the mesh: such a mesh keeps the reference tree
+      const double P = 2.0 * meshAbsMax[mi] + 1e-30, diag = std::sqrt((double) (m.bmax[0] - m.bmin[0]) * (m.bmax[0] - m.bmin[0]) +
+                                                                       (double) (m.bmax[1] - m.bmin[1]) * (m.bmax[1] - m.bmin[1]) +
+                                                                       (double) (m.bmax[2] - m.bmin[2]) * (m.bmax[2] - m.bmin[2]));
+      if (!(1.2e-5 * meshInvH[mi] * P * P < 0.01 * diag)) dm.useFast = 0;
+    }
     // refReaches tests a leaf's box only: valid when every inner box contains its children's boxes
     // (true for cy::BVH, whose inner boxes are unions); a blob that breaks this keeps the reference tree
     for (uint32_t i = 1; i < m.num_bvh_nodes && dm.useFast; ++i) {
@@ -374,6 +422,8 @@ static int PrepareScene(qa_ctx *c)
     dmeshes[mi].resFNodes = append(allFNodes[mi].data(), allFNodes[mi].size() * sizeof(DNode));
     dmeshes[mi].resFTris = append(allFTris[mi].data(), allFTris[mi].size() * sizeof(DTri));
     dmeshes[mi].resFMap = append(allFMap[mi].data(), allFMap[mi].size() * sizeof(uint32_t));
+    dmeshes[mi].resNormals = append(meshNormals[mi].data(), meshNormals[mi].size() * sizeof(float));
+    dmeshes[mi].numNormals = (uint32_t) (meshNormals[mi].size() / 4);
   }
   const uint32_t resMaterials = append(dmat.data(), dmat.size() * sizeof(DMaterial));
 

@@ -8,9 +8,10 @@
 // rules afterwards (qa_kernel.h hitMesh).  Same node format and numbering as the reference tree
 // (DNode, children adjacent on an even slot, root = 1), so one traversal routine walks both.
 //
-// Boxes are padded (1e-4 relative) and tested non-strictly: every triangle the reference's walk can
-// reach and accept is also reached here, whatever the rounding of the slab arithmetic does at box
-// faces, and flat boxes (a wall's two triangles) can be entered.
+// Boxes are tested non-strictly (flat boxes - a wall's two triangles - can be entered) and widened
+// per ray by the distance at which the reference's fp32 inside test can still accept a point that is
+// geometrically outside a triangle (qa_kernel.h hitMesh), so every triangle the reference can
+// accept inside the mesh bounds is also reached here.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -128,7 +129,9 @@ class FastBvhBuilder {
   {
     DNode &n = out_->nodes[id];
     for (int k = 0; k < 3; ++k) {
-      const float pad = 1e-4f * std::max(1.0f, std::max(std::fabs(tight.lo[k]), std::fabs(tight.hi[k])));
+      // the ray-dependent widening is applied by the traversal (hitMesh); this only absorbs the rounding of
+      // the slab arithmetic itself at the box faces
+      const float pad = 4e-7f * std::max(std::fabs(tight.lo[k]), std::fabs(tight.hi[k])) + 1e-30f;
       n.box[k] = tight.lo[k] - pad;
       n.box[3 + k] = tight.hi[k] + pad;
     }

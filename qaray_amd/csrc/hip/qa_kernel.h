@@ -295,6 +295,28 @@ __device__ __forceinline__ void boxEntryExitFast(const Ray &ray, f3 drcp, f3 bmi
   exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z));
 }
 
+// Slab tests of the library's own tree: the box is widened by `pad` on every side (folded into two
+// copies of the ray origin, so the widening costs nothing per box).  Any conservative form will do
+// here - these tests only decide where the own tree is searched, never what the reference accepts.
+__device__ __forceinline__ void boxEntryExitPadFast(f3 pLo, f3 pHi, f3 drcp, f3 bmin, f3 bmax, float &entry, float &exit_)
+{
+  const f3 p0 = (bmin - pLo) * drcp;
+  const f3 p1 = (bmax - pHi) * drcp;
+  entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z));
+  exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z));
+}
+__device__ __forceinline__ void boxEntryExitPad(f3 pLo, f3 pHi, f3 d, f3 drcp, f3 bmin, f3 bmax, float &entry, float &exit_)
+{
+  const f3 p0 = (bmin - pLo) * drcp;
+  const f3 p1 = (bmax - pHi) * drcp;
+  f3 t0, t1;
+  slab(d.x, p0.x, p1.x, t0.x, t1.x);   // a near-zero direction component leaves the axis unbounded
+  slab(d.y, p0.y, p1.y, t0.y, t1.y);
+  slab(d.z, p0.z, p1.z, t0.z, t1.z);
+  entry = qmax(t0.x, qmax(t0.y, t0.z));
+  exit_ = qmin(t1.x, qmin(t1.y, t1.z));
+}
+
 // TriObj::IntersectTriangle (src/objects/objects.cpp:212-306) on a precomputed 48-byte record
 // (three 16-byte words q0..q2, see DTri).  TriangleArea(axis, P, Q, R) =
 // (Q.u-P.u)*(R.v-P.v) - (R.u-P.u)*(Q.v-P.v) with (u,v) the two coordinates kept after dropping
@@ -425,8 +447,9 @@ struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element ord
 template <bool FAST, bool STATS>
 __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, uint32_t rootData, const Ray &ray, f3 drcp,
                                         bool fastSlab, float &hz, bool closest, uint32_t *stack, DCounters &cnt,
-                                        uint32_t &best, bool &tie)
+                                        uint32_t &best, bool &tie, float pad = 0.f)
 {
+  const f3 pLo = ray.p + F3(pad, pad, pad), pHi = ray.p - F3(pad, pad, pad);   // FAST only
   bool hasHit = false;
   int sp = 0;
   uint32_t cur = rootData;
@@ -439,7 +462,15 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
       float entry0, exit0, entry1, exit1;
       const f3 min0 = F3(asF(a0.x), asF(a0.y), asF(a0.z)), max0 = F3(asF(a0.w), asF(a1.x), asF(a1.y));
       const f3 min1 = F3(asF(b0.x), asF(b0.y), asF(b0.z)), max1 = F3(asF(b0.w), asF(b1.x), asF(b1.y));
-      if (fastSlab) {
+      if constexpr (FAST) {
+        if (fastSlab) {
+          boxEntryExitPadFast(pLo, pHi, drcp, min0, max0, entry0, exit0);
+          boxEntryExitPadFast(pLo, pHi, drcp, min1, max1, entry1, exit1);
+        } else {
+          boxEntryExitPad(pLo, pHi, ray.d, drcp, min0, max0, entry0, exit0);
+          boxEntryExitPad(pLo, pHi, ray.d, drcp, min1, max1, entry1, exit1);
+        }
+      } else if (fastSlab) {
         boxEntryExitFast(ray, drcp, min0, max0, entry0, exit0);
         boxEntryExitFast(ray, drcp, min1, max1, entry1, exit1);
       } else {
@@ -516,10 +547,11 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
                                         TriPick &pick)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  float meshExit;
   {
-    float entry, exit_;
-    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, exit_);
-    if (entry > h.z || entry > exit_) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
+    float entry;
+    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+    if (entry > h.z || entry > meshExit) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
   }
   if (m.num_faces == 0) return false;
   // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
@@ -544,8 +576,40 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     const uint32_t *fmap = RES ? reinterpret_cast<const uint32_t *>(mem.img + m.resFMap) : m.fmap;
     const float hz0 = h.z;
     uint32_t bestF = 0;
-    hasHit = walkBVH<true, false>(fnodes, ftris, m.frootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestF, tie);
+    // How far from a triangle can a point be that the reference's inside test still accepts?  The test
+    // evaluates 2-D signed areas of magnitude <= (2P)^2 (P: largest coordinate involved) in fp32 and
+    // scales them by 1 / area: the barycentrics are off by at most ~64 eps P^2 / area, i.e. the point
+    // may lie up to ~200 eps P^2 / h outside an edge (h: the smallest altitude of any triangle of the
+    // mesh, DMesh::invH = 1 / h), plus the error of the point itself.  The own tree's boxes are widened
+    // by that much for this ray, so it reaches every triangle the reference can accept up to the far
+    // side of the mesh bounds.
+    const float tEnd = qmin(meshExit, hz0);
+    const f3 pe = ray.p + ray.d * tEnd;
+    const float P = qmax(m.absMax, qmax(qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z)),
+                                        qmax(qmax(qabs(pe.x), qabs(pe.y)), qabs(pe.z))));
+    const float pad = (1.2e-5f * m.invH) * (P * P) + 1e-6f * P;
+    hasHit = walkBVH<true, false>(fnodes, ftris, m.frootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestF, tie, pad);
+    // Beyond the mesh bounds a triangle can only be "hit" by cancellation: at a distance D from the
+    // triangle the inside test is off by ~64 eps D^2 / (L h) and would have to be off by D / L, i.e.
+    // D >= h / (64 eps) ~ 2.6e5 h (all three areas then round to the same product: barycentrics 0, 0, 1).
+    // The reference does accept such a hit when nothing nearer holds the ray.  The ray meets a triangle's
+    // plane that far out only if it runs within (|o| + |mesh|) / D of parallel to it, so a miss on the
+    // own tree is trusted unless the ray is that close to one of the mesh's (few) distinct face normals;
+    // D is taken as 1e5 h.  With a hit in hand the question does not arise: D is far beyond the bounds.
     bool redo = tie;
+    if (!hasHit && hz0 > meshExit) {
+      const float o1 = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z)) + m.absMax;
+      const float theta = (1.8e-5f * m.invH) * o1;
+      const float lim = (theta * theta) * dot(ray.d, ray.d);
+      bool parallel = m.numNormals == 0;   // no list (too many distinct normals): never trust a miss
+      const float4 *nrm = reinterpret_cast<const float4 *>(mem.img + m.resNormals);
+      for (uint32_t i = 0; i < m.numNormals; ++i) {
+        const float4 n = nrm[i];
+        const float dn = dot(ray.d, F3(n.x, n.y, n.z));
+        parallel = parallel || (dn * dn <= lim);
+      }
+      redo = redo || parallel;
+    }
     if (hasHit) {
       bestTri = fmap[bestF];
       const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad

@@ -82,6 +82,10 @@ struct DMesh {
   const uint32_t *fmap;        // element of this tree -> element of the reference tree
   uint32_t frootData;
   uint32_t useFast;            // 0: this mesh is searched with the reference tree only
+  float invH;                  // 1 / smallest triangle altitude of the mesh (own-tree box widening, hitMesh)
+  float absMax;                // largest |coordinate| of the mesh bounds
+  uint32_t numNormals;         // distinct face normals (up to sign) listed at resNormals (float4 each); 0 = no list
+  uint32_t resNormals;
   uint32_t resFNodes, resFTris, resFMap;
 };
 
