@@ -281,7 +281,7 @@ static int PrepareScene(qa_ctx *c)
       }
       float absMax = 0;
       for (int k = 0; k < 3; ++k) absMax = std::max(absMax, std::max(std::fabs(m.bmin[k]), std::fabs(m.bmax[k])));
-      // distinct face normals up to sign (the DTri records hold the reference's own normalize(cross()))
+      // distinct face normals up to sign, merged within 1e-5 (the DTri records hold the reference's own normalize(cross()))
       {
         std::vector<float> &nl = meshNormals[mi];
         bool overflow = false;
@@ -290,7 +290,12 @@ static int PrepareScene(qa_ctx *c)
           if (!(N[0] == N[0])) continue;   // degenerate triangle: NaN normal, never accepted
           bool seen = false;
           for (size_t q = 0; q + 3 < nl.size() + 1 && !seen; q += 4)
-            seen = (nl[q] == N[0] && nl[q + 1] == N[1] && nl[q + 2] == N[2]) || (nl[q] == -N[0] && nl[q + 1] == -N[1] && nl[q + 2] == -N[2]);
+          {
+            // same direction up to sign within 1e-5 (the kernel's parallelism threshold allows for it)
+            const float dp = std::fabs(nl[q] * N[0] + nl[q + 1] * N[1] + nl[q + 2] * N[2]);
+            const float cx = nl[q + 1] * N[2] - nl[q + 2] * N[1], cy = nl[q + 2] * N[0] - nl[q] * N[2], cz = nl[q] * N[1] - nl[q + 1] * N[0];
+            seen = dp > 0.5f && std::sqrt(cx * cx + cy * cy + cz * cz) < 1e-5f;
+          }
           if (!seen) {
             if (nl.size() >= 4 * 24) overflow = true;
             else { nl.push_back(N[0]); nl.push_back(N[1]); nl.push_back(N[2]); nl.push_back(0.f); }
@@ -311,7 +316,9 @@ static int PrepareScene(qa_ctx *c)
         const double costRef = m.num_bvh_nodes > 1 ? TreeCost(dn.data(), nodes[1].data, rootBox) : 0;
         const double costFast = TreeCost(fb.nodes.data(), fb.rootData, rootBox);
         fastCost[mi] = {costRef, costFast};
-        if (getenv("QA_FAST_VERBOSE")) fprintf(stderr, "mesh %u: %u triangles, expected ray cost reference tree %.2f, own tree %.2f (depth %u)\n", mi, m.num_faces, costRef, costFast, fb.depth);
+        if (getenv("QA_FAST_VERBOSE"))
+          fprintf(stderr, "mesh %u: %u triangles, expected ray cost reference tree %.2f, own tree %.2f (depth %u), smallest altitude %g, |coord| <= %g, %zu distinct normals\n",
+                  mi, m.num_faces, costRef, costFast, fb.depth, hMin, (double) absMax, meshNormals[mi].size() / 4);
       }
       allFNodes[mi] = fb.nodes;
       allFMap[mi] = fb.order;

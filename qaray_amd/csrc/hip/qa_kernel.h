@@ -583,10 +583,9 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     // mesh, DMesh::invH = 1 / h), plus the error of the point itself.  The own tree's boxes are widened
     // by that much for this ray, so it reaches every triangle the reference can accept up to the far
     // side of the mesh bounds.
-    const float tEnd = qmin(meshExit, hz0);
-    const f3 pe = ray.p + ray.d * tEnd;
-    const float P = qmax(m.absMax, qmax(qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z)),
-                                        qmax(qmax(qabs(pe.x), qabs(pe.y)), qabs(pe.z))));
+    // (every point of the ray up to the far side of the bounds lies between the origin and the bounds)
+    const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
+    const float P = qmax(m.absMax, oMax);
     const float pad = (1.2e-5f * m.invH) * (P * P) + 1e-6f * P;
     hasHit = walkBVH<true, false>(fnodes, ftris, m.frootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestF, tie, pad);
     // Beyond the mesh bounds a triangle can only be "hit" by cancellation: at a distance D from the
@@ -598,14 +597,13 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     // D is taken as 1e5 h.  With a hit in hand the question does not arise: D is far beyond the bounds.
     bool redo = tie;
     if (!hasHit && hz0 > meshExit) {
-      const float o1 = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z)) + m.absMax;
-      const float theta = (1.8e-5f * m.invH) * o1;
+      const float theta = (1.8e-5f * m.invH) * (oMax + m.absMax) + 2e-5f;   // + the tolerance the normal list was merged with
       const float lim = (theta * theta) * dot(ray.d, ray.d);
       bool parallel = m.numNormals == 0;   // no list (too many distinct normals): never trust a miss
       const float4 *nrm = reinterpret_cast<const float4 *>(mem.img + m.resNormals);
       for (uint32_t i = 0; i < m.numNormals; ++i) {
         const float4 n = nrm[i];
-        const float dn = dot(ray.d, F3(n.x, n.y, n.z));
+        const float dn = __builtin_fmaf(ray.d.x, n.x, __builtin_fmaf(ray.d.y, n.y, ray.d.z * n.z));   // not reference arithmetic: fused is fine
         parallel = parallel || (dn * dn <= lim);
       }
       redo = redo || parallel;
