@@ -547,15 +547,16 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
                                         TriPick &pick)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
+  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
   float meshExit;
   {
     float entry;
-    boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+    if (fastSlab) boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+    else boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
     if (entry > h.z || entry > meshExit) return false;  // Box::IntersectRay, src/core/box.cpp:94-128
   }
   if (m.num_faces == 0) return false;
-  // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
-  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
   const uint4 *nodes = RES ? mem.img + m.resNodes : reinterpret_cast<const uint4 *>(m.nodes);
   const uint4 *tris = RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris);
   const uint4 *shade = RES ? mem.img + m.resShade : reinterpret_cast<const uint4 *>(m.shade);
