@@ -159,6 +159,8 @@ static int PrepareScene(qa_ctx *c)
   std::vector<float> meshInvH(h->num_meshes, 0.f), meshAbsMax(h->num_meshes, 0.f);
   std::vector<std::vector<float>> meshNormals(h->num_meshes);   // x, y, z, 0 per distinct face normal; empty = too many
   uint32_t stackNeedMax = 1;
+  uint64_t totalFaces = 0;
+  for (uint32_t mi = 0; mi < h->num_meshes; ++mi) totalFaces += mesh[mi].num_faces;
   for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
     const qa_mesh &m = mesh[mi];
     if (!inside(m.off_bvh_nodes, (uint64_t) m.num_bvh_nodes * sizeof(qa_bvh_node)) ||
@@ -306,6 +308,14 @@ static int PrepareScene(qa_ctx *c)
       meshInvH[mi] = hMin < 1e300 ? (float) (1.0 / hMin) : 0.f;
       meshAbsMax[mi] = absMax;
       FastBvh fb;
+      // only LDS-resident scenes search their own trees, and residency needs the whole image within
+      // 40 KB (~140 B per triangle before the own tree): skip the build where that is out of reach
+      if (totalFaces > 512) {
+        fb.nodes.assign(2, DNode{});
+        fb.order.clear();
+        allFNodes[mi] = fb.nodes;
+        fastCost[mi] = {0.0, 0.0};
+      } else {
       const unsigned leafMax = getenv("QA_FAST_LEAF") ? (unsigned) atoi(getenv("QA_FAST_LEAF")) : 2u;
       try { FastBvhBuilder(bounds.data(), m.num_faces, leafMax).Run(fb); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
       if (fb.nodes.size() & 1) fb.nodes.push_back(DNode{});
@@ -326,6 +336,7 @@ static int PrepareScene(qa_ctx *c)
       for (uint32_t i = 0; i < m.num_faces; ++i) allFTris[mi][i] = dt[fb.order[i]];
       if (fb.depth > stackNeed) stackNeed = fb.depth;
       if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
+      }
     }
     // texture vertices per triangle (element order); a mesh must have them on every face or none
     const float *VT = QA_BLOB_PTR(float, blob, m.off_texcoords);
@@ -360,7 +371,7 @@ static int PrepareScene(qa_ctx *c)
     dm.num_nodes = m.num_bvh_nodes;
     dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
     dm.frootData = (m.num_faces && allFNodes[mi].size() > 1) ? allFNodes[mi][1].data : QA_DONE;
-    dm.useFast = (m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
+    dm.useFast = (totalFaces <= 512 && m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
     dm.invH = meshInvH[mi];
     dm.absMax = meshAbsMax[mi];
     {
