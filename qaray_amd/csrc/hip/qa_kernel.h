@@ -972,8 +972,14 @@ struct Path {
 // caustics map, and from the photon map instead of bouncing when the ray already comes from a
 // diffuse bounce (MtlBlinn_PhotonMap.cpp:349-359,426-458).  The gathers draw no random numbers, so
 // they are evaluated at the hit (also by AREA variants).
+// Waves per SIMD the register allocator must leave room for.  The LDS-resident kernel without lights
+// (the Cornell box class: VALU-issue bound, smallest register footprint) gains from a fifth wave (+5 %);
+// every other variant loses more to the extra spills than the added latency hiding returns
+// (resident glass-sphere room -36 %, project7_object -8 %, glossy caustics -10 %); 6 loses everywhere.
+#define QA_WAVES_FOR(RES, LIGHTS) (((RES) && !(LIGHTS)) ? QA_MIN_WAVES + 1 : QA_MIN_WAVES)
+
 template <bool RES, bool LIGHTS, bool TEX, bool AREA, bool STATS, bool PHOTON = false>
-__global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate(const DScene sc, const RenderParams rp)
+__global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integrate(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
   SceneMem<RES> mem;
