@@ -123,6 +123,18 @@ int qa_reset_counters(qa_ctx *ctx);
 int qa_get_kernel_time(qa_ctx *ctx, double *total_ms, uint64_t *launches);
 int qa_reset_kernel_time(qa_ctx *ctx);
 
+/* Which integrator the uploaded scene runs on, e.g. "qa_integrate<RES=1,LIGHTS=0,TEX=0,AREA=0>" (one persistent
+ * megakernel, LDS-resident scene) or "staged: wf_logic + wf_cull + wf_trace + wf_redo" (scenes whose
+ * geometry does not fit LDS).  The pointer stays valid until the next scene upload. */
+const char *qa_get_kernel_name(qa_ctx *ctx);
+/* Diagnostics of the staged integrator since the last qa_reset_counters (synchronises):
+ * [0] passes, [1] closest-hit rays, [2] shadow rays, [3] BVH jobs queued, [4] rays repeated exactly,
+ * [5] jobs finished, [6] node steps, [7] leaf steps, [8] triangle tests, [9] hits that failed the order check,
+ * [10] jobs suspended by the step budget, [11] lane slots used in traversal rounds, [12] traversal rounds (waves).
+ * Lane utilisation of the traversal = [11] / (64 * [12]); geometry bytes = [6] * 64 + [8] * 48. */
+#define QA_STAGED_STATS 13
+int qa_get_staged_stats(qa_ctx *ctx, uint64_t out[QA_STAGED_STATS]);
+
 /* Launch geometry (0 = library default). blocks_per_cu * CUs persistent workgroups of `threads`. */
 int qa_set_launch_config(qa_ctx *ctx, int blocks_per_cu, int threads_per_block);
 

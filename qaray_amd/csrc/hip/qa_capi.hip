@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "qa_kernel_sm.h"
+#include "qa_kernel.h"
 #include "qa_ctx.h"
 #include "qa_fastbvh.h"
 
@@ -54,18 +54,6 @@ static KernelFn PickShading(bool lights, bool tex, bool area)
   if (lights) return (KernelFn) qa_integrate<RES, true, false, false, STATS>;
   return (KernelFn) qa_integrate<RES, false, false, false, STATS>;
 }
-template <bool RES, bool STATS>
-static KernelFn PickShadingSM(bool lights, bool tex)
-{
-  if (tex) return (KernelFn) qa_integrate_sm<RES, true, true, STATS>;
-  if (lights) return (KernelFn) qa_integrate_sm<RES, true, false, STATS>;
-  return (KernelFn) qa_integrate_sm<RES, false, false, STATS>;
-}
-static KernelFn PickKernelSM(bool resident, bool lights, bool tex, bool stats)
-{
-  if (resident) return stats ? PickShadingSM<true, true>(lights, tex) : PickShadingSM<true, false>(lights, tex);
-  return stats ? PickShadingSM<false, true>(lights, tex) : PickShadingSM<false, false>(lights, tex);
-}
 static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool stats)
 {
   if (resident) return stats ? PickShading<true, true>(lights, tex, area) : PickShading<true, false>(lights, tex, area);
@@ -77,25 +65,15 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
 static int SelectKernel(qa_ctx *c)
 {
   const bool lights = c->ds.num_lights > 0;
-  // kernel family: the interleaved state machine (suspendable casts) unless the scene has area
-  // lights; QA_KERNEL=lockstep|sm overrides for A/B runs
-  bool sm = false;  // measured slower than the lockstep kernel on every scene so far
-  if (const char *e = getenv("QA_KERNEL")) {
-    if (!strcmp(e, "lockstep")) sm = false;
-    else if (!strcmp(e, "sm") && !c->area) sm = true;
-  }
-  c->useSM = sm;
-  if (sm) {
-    c->kernel = PickKernelSM(c->resident, lights, c->textured, false);
-    c->kernelStats = PickKernelSM(c->resident, lights, c->textured, true);
-  } else {
-    c->kernel = PickKernel(c->resident, lights, c->textured, c->area, false);
-    c->kernelStats = PickKernel(c->resident, lights, c->textured, c->area, true);
-  }
+  c->kernel = PickKernel(c->resident, lights, c->textured, c->area, false);
+  c->kernelStats = PickKernel(c->resident, lights, c->textured, c->area, true);
   int resident = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
+  char name[160];
+  snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) lights, (int) c->textured, (int) c->area);
+  c->kernelName = c->wf.eligible ? "staged: wf_logic + wf_cull + wf_trace + wf_redo" : name;
   return QA_OK;
 }
 
@@ -392,6 +370,7 @@ static int PrepareScene(qa_ctx *c)
           if (!(nodes[q].box[k] >= nodes[i].box[k] && nodes[q].box[k + 3] <= nodes[i].box[k + 3])) dm.useFast = 0;
     }
     dm.stackNeed = stackNeed;
+    dm.gateIsRoot = (m.num_bvh_nodes > 1 && memcmp(nodes[1].box, m.bmin, 12) == 0 && memcmp(nodes[1].box + 3, m.bmax, 12) == 0) ? 1u : 0u;
     int rc;
     if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, dt, &dm.tris)) != QA_OK) return rc;
@@ -538,6 +517,7 @@ static int PrepareScene(qa_ctx *c)
     ds.rootIdentity = (memcmp(inst[0].tm, I, 36) == 0 && memcmp(inst[0].itm, I, 36) == 0 && memcmp(inst[0].pos, Z, 12) == 0) ? 1 : 0;
   }
   c->haveScene = true;
+  SelectStaged(c);
   return SelectKernel(c);
 }
 
@@ -580,7 +560,6 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   rp.seed = seed;
   rp.tile_row0 = tile_row0; rp.tile_row_step = tile_row_step; rp.own_tile_rows = ownRows; rp.pad = 0;
   rp.sync_samples = c->syncSamples < 0 ? c->syncAuto : c->syncSamples;
-  rp.sm_gen_thresh = c->smGen; rp.sm_inst_thresh = c->smInst; rp.sm_trav_steps = c->smTrav;
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
   rp.tile_order = nullptr;
@@ -645,8 +624,14 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
   else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
   HIP_TRY(hipEventRecord(ev.a, s));
-  hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
-  HIP_TRY(hipGetLastError());
+  if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
+    // scenes whose geometry does not fit LDS: the staged integrator (qa_wf.h), one event pair around the frame
+    rc = RenderStaged(c, ds, rp, s);
+    if (rc != QA_OK) { c->freeEvents.push_back(ev); return rc; }
+  } else {
+    hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(ev.b, s));
   c->pending.push_back(ev);
   c->launches++;
@@ -762,9 +747,8 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   }
   *c->hStop = 0;
   if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
-  if (const char *e = getenv("QA_SM_GEN")) c->smGen = atoi(e);
-  if (const char *e = getenv("QA_SM_INST")) c->smInst = atoi(e);
-  if (const char *e = getenv("QA_SM_TRAV")) c->smTrav = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 128u;
+  if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
@@ -779,6 +763,7 @@ int qa_ctx_destroy(qa_ctx *c)
   (void) hipSetDevice(c->device);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   FreeScene(c);
+  FreeStaged(c);
   for (EventPair &ev : c->pending) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
   for (EventPair &ev : c->freeEvents) { (void) hipEventDestroy(ev.a); (void) hipEventDestroy(ev.b); }
   if (c->dHalton) (void) hipFree(c->dHalton);
@@ -920,7 +905,29 @@ int qa_reset_counters(qa_ctx *c)
   int rc = qa_synchronize(c);
   if (rc != QA_OK) return rc;
   HIP_TRY(hipMemset(c->dCounters, 0, sizeof(DCounters)));
+  if (c->wf.dStats) HIP_TRY(hipMemset(c->wf.dStats, 0, sizeof(WfStats)));
+  c->wf.iterations = c->wf.raysClosest = c->wf.raysShadow = c->wf.jobs = c->wf.redo = 0;
   return QA_OK;
+}
+
+int qa_get_staged_stats(qa_ctx *c, uint64_t out[QA_STAGED_STATS])
+{
+  if (!c || !out) return Fail(QA_EINVAL, "null argument");
+  int rc = qa_synchronize(c);
+  if (rc != QA_OK) return rc;
+  WfStats st;
+  memset(&st, 0, sizeof(st));
+  if (c->wf.dStats) HIP_TRY(hipMemcpy(&st, c->wf.dStats, sizeof(st), hipMemcpyDeviceToHost));
+  const uint64_t v[QA_STAGED_STATS] = {c->wf.iterations, c->wf.raysClosest, c->wf.raysShadow, c->wf.jobs, c->wf.redo, st.jobs, st.nodeSteps,
+                                       st.leafSteps, st.triTests, st.redo, st.suspended, st.laneSlots, st.waveRounds};
+  memcpy(out, v, sizeof(v));
+  return QA_OK;
+}
+
+const char *qa_get_kernel_name(qa_ctx *c)
+{
+  if (!c || !c->haveScene) return "";
+  return c->kernelName.c_str();
 }
 
 int qa_get_kernel_time(qa_ctx *c, double *total_ms, uint64_t *launches)

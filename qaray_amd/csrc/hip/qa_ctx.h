@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "qa_scene_dev.h"
+#include "qa_wf_types.h"
 #include "qaray_hip.h"
 
 using namespace qa;
@@ -23,6 +24,23 @@ inline int Fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 
 struct EventPair { hipEvent_t a, b; };
+
+// Host side of the staged integrator (qa_wf.hip): buffers are kept between frames
+struct WfHost {
+  bool eligible = false;        // the uploaded scene can run staged (SelectStaged)
+  int numLights = 0;            // non-ambient lights
+  int32_t lightIdx[QA_WF_MAX_LIGHTS] = {0, 0, 0, 0};
+  WfBuf buf{};
+  size_t capSlots = 0;
+  int capLights = -1;
+  std::vector<void *> allocs;
+  WfCounters *dCtr = nullptr, *hCtr = nullptr;   // one per iteration of a chunk (device / pinned host)
+  WfStats *dStats = nullptr;
+  // diagnostics of the frames rendered since the last reset
+  uint64_t iterations = 0, raysClosest = 0, raysShadow = 0, jobs = 0, redo = 0;
+  int traceBlocksPerCU = 0;     // 0 = ask the occupancy API at the first frame
+  uint32_t budget = 128;        // BVH steps a job may take per pass (QA_WF_BUDGET)
+};
 
 struct qa_ctx {
   int device = 0;
@@ -54,11 +72,10 @@ struct qa_ctx {
   int blocksPerCU = 0, blocksPerCUAuto = 2, threads = QA_BLOCK;  // 0 = use the occupancy-derived value
   void (*kernel)(const DScene, const RenderParams) = nullptr;
   void (*kernelStats)(const DScene, const RenderParams) = nullptr;
-  bool resident = false, textured = false, area = false, useSM = false;
+  bool resident = false, textured = false, area = false;
   int syncAuto = 0;
   uint32_t *dOrder = nullptr;   // tile launch order of the last region shape
   uint64_t orderKey = 0;
-  int smGen = 32, smInst = 16, smTrav = 16;
   int syncSamples = -1;  // -1: decide per scene (SelectKernel), 0/1 forced by QA_SYNC
   uint32_t stackDepth = 32;
   size_t ldsBytes = 0;
@@ -74,9 +91,16 @@ struct qa_ctx {
   qa_photon_params photonParams{};
   uint64_t photonEmitted[2] = {0, 0}, photonEmissions[2] = {0, 0};
   std::vector<qa_photon> hostPhotons[2];   // balanced, [0] unused
+  WfHost wf;
+  std::string kernelName;
 };
 
 void FreePhotonMaps(qa_ctx *c);  // qa_photon.hip
+// qa_wf.hip
+void FreeStaged(qa_ctx *c);
+void SelectStaged(qa_ctx *c);
+bool StagedTakes(const qa_ctx *c, uint32_t flags, int spp_max, int max_bounce, size_t slots);
+int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_t s);
 
 inline void FreeScene(qa_ctx *c)
 {

@@ -87,6 +87,7 @@ struct DMesh {
   uint32_t numNormals;         // distinct face normals (up to sign) listed at resNormals (float4 each); 0 = no list
   uint32_t resNormals;
   uint32_t resFNodes, resFTris, resFMap;
+  uint32_t gateIsRoot;         // the mesh bounds equal the root box of the reference tree bit for bit
 };
 
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
@@ -154,8 +155,7 @@ struct RenderParams {
   int32_t spp_min, spp_max, max_bounce;
   uint32_t seed;
   int32_t tile_row0, tile_row_step, own_tile_rows, pad;  // which 8-row strips of the region
-  int32_t sm_gen_thresh, sm_inst_thresh, sm_trav_steps;
-  int32_t sync_samples;        // 1: a wave starts its lanes' next samples together (coherent primary rays)  // scheduling knobs of qa_integrate_sm
+  int32_t sync_samples;        // 1: a wave starts its lanes' next samples together (coherent primary rays)
   float *rgb;                  // region-local outputs
   float *depth;
   uint32_t *ns;

@@ -78,6 +78,9 @@ def lib():
         L.qa_get_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.qa_reset_kernel_time.argtypes = [C.c_void_p]
         L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.qa_get_kernel_name.argtypes = [C.c_void_p]
+        L.qa_get_kernel_name.restype = C.c_char_p
+        L.qa_get_staged_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.qa_photon_maps_build.argtypes = [C.c_void_p, C.POINTER(PhotonParams), C.c_uint32]
         L.qa_photon_maps_clear.argtypes = [C.c_void_p]
         L.qa_photon_maps_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -219,6 +222,22 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         _check(lib().qa_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_name(self):
+        """The integrator the uploaded scene runs on (megakernel variant or the staged pipeline)."""
+        return lib().qa_get_kernel_name(self._h).decode()
+
+    STAGED_FIELDS = ("passes", "rays_closest", "rays_shadow", "jobs_queued", "rays_redone", "jobs_done", "node_steps", "leaf_steps",
+                     "tri_tests", "order_check_failed", "jobs_suspended", "lane_slots", "wave_rounds")
+
+    def staged_stats(self):
+        """Diagnostics of the staged integrator since the last reset_counters()."""
+        v = (C.c_uint64 * len(self.STAGED_FIELDS))()
+        _check(lib().qa_get_staged_stats(self._h, v))
+        d = {k: int(x) for k, x in zip(self.STAGED_FIELDS, v)}
+        d["lane_utilisation"] = d["lane_slots"] / (64.0 * d["wave_rounds"]) if d["wave_rounds"] else 0.0
+        d["geometry_bytes"] = d["node_steps"] * 64 + d["tri_tests"] * 48
+        return d
 
     def reset_kernel_time(self):
         _check(lib().qa_reset_kernel_time(self._h))
