@@ -13,6 +13,7 @@
 #include "qa_kernel.h"
 #include "qa_ctx.h"
 #include "qa_fastbvh.h"
+#include "qa_widebvh.h"
 
 // core/sampler.cpp:31-40, evaluated on the host in the reference's fp32 order
 static float HaltonF(int index, int base)
@@ -133,6 +134,8 @@ static int PrepareScene(qa_ctx *c)
   std::vector<std::vector<DNode>> allFNodes(h->num_meshes);     // the library's own trees (qa_fastbvh.h)
   std::vector<std::vector<DTri>> allFTris(h->num_meshes);
   std::vector<std::vector<uint32_t>> allFMap(h->num_meshes);
+  std::vector<WideBvh> allWide(h->num_meshes);                  // 4-wide trees over the reference leaves (qa_widebvh.h)
+  std::vector<MeshSlack> meshSlack(h->num_meshes, MeshSlack{0.f, 0.f});
   std::vector<std::pair<double, double>> fastCost(h->num_meshes, {0.0, 0.0});   // expected ray cost: reference tree, own tree
   std::vector<float> meshInvH(h->num_meshes, 0.f), meshAbsMax(h->num_meshes, 0.f);
   std::vector<std::vector<float>> meshNormals(h->num_meshes);   // x, y, z, 0 per distinct face normal; empty = too many
@@ -293,6 +296,25 @@ static int PrepareScene(qa_ctx *c)
         fb.order.clear();
         allFNodes[mi] = fb.nodes;
         fastCost[mi] = {0.0, 0.0};
+        // global-memory scene: the 4-wide tree over the reference leaves, and the inside test's fp32 slack
+        if (m.num_faces > 0 && m.num_bvh_nodes > 1 && !(getenv("QA_WIDE") && atoi(getenv("QA_WIDE")) == 0)) {
+          try {
+            WideBvhBuilder(dn.data(), m.num_bvh_nodes).Run(allWide[mi]);
+            std::vector<float> ev(9 * (size_t) m.num_faces);
+            for (uint32_t e = 0; e < m.num_faces; ++e) {
+              const qa_face &f = faces[elements[e]];
+              for (int v = 0; v < 3; ++v) memcpy(&ev[9 * (size_t) e + 3 * v], V + 3 * (size_t) f.v[v], 12);
+            }
+            meshSlack[mi] = ComputeMeshSlack(dt.data(), m.num_faces, ev.data());
+          } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+          const uint32_t need = 3 * allWide[mi].depth + 2;
+          if (need > stackNeed) stackNeed = need;
+          if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
+          if (getenv("QA_FAST_VERBOSE"))
+            fprintf(stderr, "mesh %u: %u triangles, reference tree %u nodes depth %u; wide tree %zu nodes depth %u; inside-test slack %g, cancel distance %g, |coord| <= %g\n",
+                    mi, m.num_faces, m.num_bvh_nodes, stackNeed, allWide[mi].nodes.size(), allWide[mi].depth, (double) meshSlack[mi].nearPad,
+                    (double) meshSlack[mi].cancelDist, (double) absMax);
+        }
       } else {
       const unsigned leafMax = getenv("QA_FAST_LEAF") ? (unsigned) atoi(getenv("QA_FAST_LEAF")) : 2u;
       try { FastBvhBuilder(bounds.data(), m.num_faces, leafMax).Run(fb); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
@@ -370,6 +392,23 @@ static int PrepareScene(qa_ctx *c)
           if (!(nodes[q].box[k] >= nodes[i].box[k] && nodes[q].box[k + 3] <= nodes[i].box[k + 3])) dm.useFast = 0;
     }
     dm.stackNeed = stackNeed;
+    dm.wrootWord = allWide[mi].rootWord;
+    dm.nearPad = meshSlack[mi].nearPad;
+    dm.cancelDist = meshSlack[mi].cancelDist;
+    {
+      const double diag = std::sqrt((double) (m.bmax[0] - m.bmin[0]) * (m.bmax[0] - m.bmin[0]) + (double) (m.bmax[1] - m.bmin[1]) * (m.bmax[1] - m.bmin[1]) +
+                                    (double) (m.bmax[2] - m.bmin[2]) * (m.bmax[2] - m.bmin[2]));
+      // needle triangles would widen every box by a sizeable part of the mesh: such a mesh keeps the reference tree
+      dm.useWide = (!allWide[mi].nodes.empty() && meshSlack[mi].nearPad < 0.01 * diag) ? 1u : 0u;
+    }
+    // the order check tests a leaf's box only: valid when every inner box of the reference tree contains its children's
+    for (uint32_t i = 1; i < m.num_bvh_nodes && dm.useWide; ++i) {
+      if (nodes[i].data & QA_BVH_LEAF_BIT) continue;
+      const uint32_t ch = nodes[i].data & QA_BVH_CHILD_MASK;
+      for (uint32_t q = ch; q < ch + 2; ++q)
+        for (int k = 0; k < 3; ++k)
+          if (!(nodes[q].box[k] >= nodes[i].box[k] && nodes[q].box[k + 3] <= nodes[i].box[k + 3])) dm.useWide = 0;
+    }
     dm.gateIsRoot = (m.num_bvh_nodes > 1 && memcmp(nodes[1].box, m.bmin, 12) == 0 && memcmp(nodes[1].box + 3, m.bmax, 12) == 0) ? 1u : 0u;
     int rc;
     if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;
@@ -378,6 +417,7 @@ static int PrepareScene(qa_ctx *c)
     if ((rc = DeviceCopy(c, allFNodes[mi], &dm.fnodes)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, allFTris[mi], &dm.ftris)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, allFMap[mi], &dm.fmap)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, allWide[mi].nodes, &dm.wnodes)) != QA_OK) return rc;
   }
 
   // ---- material table (plain colours) -----------------------------------------------------------

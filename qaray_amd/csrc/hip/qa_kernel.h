@@ -512,6 +512,77 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
   return hasHit;
 }
 
+// One walk of the library's 4-wide tree over the reference tree's leaves (qa_widebvh.h).  Boxes are widened by
+// `pad` (folded into two copies of the origin) and tested non-strictly, so every reference leaf the ray can have
+// an accepted hit in is visited; children are entered nearest first.  Leaves are the reference's own (same
+// triangle ranges, element order); `tie` is raised when a triangle passes the inside test at exactly the
+// distance already held.  closest = false stops at the first accepted triangle.  `stack`: LDS, stride QA_BLOCK,
+// `cap` entries - on overflow `tie` is raised too (the caller then repeats the query on the reference tree).
+__device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uint32_t rootWord, const Ray &ray, f3 drcp, float pad,
+                                         float &hz, bool closest, uint32_t *stack, uint32_t cap, uint32_t &best, bool &tie)
+{
+  const f3 pLo = ray.p + F3(pad, pad, pad), pHi = ray.p - F3(pad, pad, pad);
+  const float INF = __builtin_inff();
+  bool hasHit = false;
+  uint32_t sp = 0;
+  uint32_t cur = rootWord;
+  while (cur != QA_DONE) {
+    while (!(cur & QA_BVH_LEAF_BIT)) {
+      const uint4 *nd = wn + 8 * (size_t) cur;
+      const uint4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hzz = nd[5], ch = nd[6];
+      float k0, k1, k2, k3;
+      uint32_t w0 = ch.x, w1 = ch.y, w2 = ch.z, w3 = ch.w;
+#define QA_WIDE_CHILD(K, W, LX, LY, LZ, HX, HY, HZ)                                                                           \
+      {                                                                                                                        \
+        const f3 p0 = (F3(asF(LX), asF(LY), asF(LZ)) - pLo) * drcp, p1 = (F3(asF(HX), asF(HY), asF(HZ)) - pHi) * drcp;        \
+        const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z)); \
+        const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z)); \
+        K = (W != QA_DONE && en <= hz && en <= ex) ? en : INF;                                                                 \
+      }
+      QA_WIDE_CHILD(k0, w0, lx.x, ly.x, lz.x, hx.x, hy.x, hzz.x)
+      QA_WIDE_CHILD(k1, w1, lx.y, ly.y, lz.y, hx.y, hy.y, hzz.y)
+      QA_WIDE_CHILD(k2, w2, lx.z, ly.z, lz.z, hx.z, hy.z, hzz.z)
+      QA_WIDE_CHILD(k3, w3, lx.w, ly.w, lz.w, hx.w, hy.w, hzz.w)
+#undef QA_WIDE_CHILD
+#define QA_WIDE_CE(KA, WA, KB, WB)                                  \
+      {                                                             \
+        const bool sw = KA > KB;                                    \
+        const float tk = sw ? KB : KA;                              \
+        KB = sw ? KA : KB;                                          \
+        KA = tk;                                                    \
+        const uint32_t tw = sw ? WB : WA;                           \
+        WB = sw ? WA : WB;                                          \
+        WA = tw;                                                    \
+      }
+      QA_WIDE_CE(k0, w0, k1, w1)
+      QA_WIDE_CE(k2, w2, k3, w3)
+      QA_WIDE_CE(k0, w0, k2, w2)
+      QA_WIDE_CE(k1, w1, k3, w3)
+      QA_WIDE_CE(k1, w1, k2, w2)
+#undef QA_WIDE_CE
+      // nearest child next, the others stacked farthest first
+      if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
+      if (k2 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w2; else tie = true; }
+      if (k1 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w1; else tie = true; }
+      if (k0 < INF) cur = w0;
+      else cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
+    }
+    if (cur == QA_DONE) break;
+    const uint32_t count = ((cur >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+    const uint32_t first = cur & QA_BVH_OFFSET_MASK;
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint4 *t = tris + 3 * (size_t) (first + i);
+      if (hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie)) {
+        hasHit = true;
+        best = first + i;
+        if (!closest) return true;
+      }
+    }
+    cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
+  }
+  return hasHit;
+}
+
 // Would the reference's walk have reached the leaf `leaf` of its tree?  It enters a node when the
 // strict box test passes against the distance held at that moment.  Every inner box of the tree is
 // the union of its children's boxes (min / max of the same floats), and the slab arithmetic is
@@ -544,7 +615,7 @@ __device__ __forceinline__ bool refReaches(const uint4 *nodes, uint32_t leaf, co
 template <bool RES, bool STATS>
 __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
                                         bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt,
-                                        TriPick &pick)
+                                        TriPick &pick, uint32_t stackCap = 0xFFFFu)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
   // wave-uniform choice: the exact MIN/MAX/threshold form only when some lane needs it
@@ -567,8 +638,33 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
   // trip, and the SAH tree's longer chains of small nodes cost more than its fewer triangle tests save
   // (measured: tower scene 182 -> 199 ms, glossy caustics 52 -> 61 ms, project7_object 99 -> 93 ms),
   // while carrying both walks in one kernel costs those scenes 5 - 10 % in registers alone.
-  if constexpr (STATS || !RES) {
+  if constexpr (STATS) {
     hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+  } else if constexpr (!RES) {
+    // Global-memory meshes: the 4-wide tree over the reference tree's leaves (qa_widebvh.h) - a third of the
+    // dependent node reads - with the answer checked against the reference's rules: the found triangle's leaf must
+    // pass the reference's strict box test at the found distance (refReaches: then the reference's walk, whose
+    // running distance is at least that, reaches the triangle too), and no tie may have been seen.  A miss needs no
+    // check: every reference leaf the ray can have an accepted hit in is visited (boxes are unions of the
+    // reference's leaf boxes, widened by the fp32 slack of its inside test).  Otherwise, and for ray origins so
+    // far out that the inside test's areas can cancel, the lane walks the reference tree as the reference does.
+    const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
+    bool redo = true;
+    const float hz0 = h.z;
+    if (m.useWide && 2.f * (oMax + m.absMax) < m.cancelDist) {
+      const float pad = m.nearPad + 1e-6f * (oMax + m.absMax);
+      hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), tris, m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
+      redo = tie;
+      if (hasHit && !redo) {
+        const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad
+        redo = !refReaches(nodes, leaf, ray, drcp, fastSlab, closest ? h.z : hz0);
+      }
+    }
+    if (redo) {
+      h.z = hz0;
+      tie = false;
+      hasHit = walkBVH<false, false>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+    }
   } else if (!m.useFast) {
     hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
   } else {
@@ -671,7 +767,7 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
     } else {
       const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
       TriPick pick;
-      hit = hitMesh<RES, STATS>(mem, m, r, h, k, true, stack, cnt, pick);
+      hit = hitMesh<RES, STATS>(mem, m, r, h, k, true, stack, cnt, pick, sc.stackDepth);
       if (TEX && hit && m.hasVT) {
         const uint4 *t = (RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris)) + 3 * (size_t) pick.tri;
         const float *vt = m.vt + 6 * (size_t) pick.tri;
@@ -715,7 +811,7 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
     else {
       TriPick pick;
-      hit = hitMesh<RES, STATS>(mem, meshAt<RES>(sc, instAt<RES>(sc, k).mesh), r, h, k, false, stack, cnt, pick);
+      hit = hitMesh<RES, STATS>(mem, meshAt<RES>(sc, instAt<RES>(sc, k).mesh), r, h, k, false, stack, cnt, pick, sc.stackDepth);
     }
     if (hit) return 0.0f;
   }

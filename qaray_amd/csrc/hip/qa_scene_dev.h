@@ -64,6 +64,17 @@ static_assert(sizeof(DMaterial) == 96, "DMaterial must be 6 x 16 bytes");
 #define QA_MTL_SPECULAR_LOBES 1u
 #define QA_MTL_HAS_SPECULAR 2u
 
+// Node of the library's own 4-wide search tree for global-memory meshes (qa_widebvh.h): four child boxes in SoA
+// form, four child words (inner: node index; leaf: the reference leaf's own word = flag + triangle range;
+// QA_DONE: empty slot) and the reference-tree ids of leaf children.  8 x 16 bytes.
+struct alignas(128) DWideNode {
+  float lo[3][4];
+  float hi[3][4];
+  uint32_t child[4];
+  uint32_t refLeaf[4];
+};
+static_assert(sizeof(DWideNode) == 128, "DWideNode must be 8 x 16 bytes");
+
 struct DMesh {
   float bmin[3], bmax[3];
   const DNode *nodes;          // [num_nodes], root = 1 (global memory copy)
@@ -88,6 +99,12 @@ struct DMesh {
   uint32_t resNormals;
   uint32_t resFNodes, resFTris, resFMap;
   uint32_t gateIsRoot;         // the mesh bounds equal the root box of the reference tree bit for bit
+  // the 4-wide tree over the reference tree's leaves (global-memory scenes, non-counting kernels)
+  const DWideNode *wnodes;
+  uint32_t wrootWord;          // child word of the root
+  uint32_t useWide;
+  float nearPad;               // fp32 slack of the reference's inside test (qa_widebvh.h ComputeMeshSlack)
+  float cancelDist;            // ray origins farther out than this keep the reference tree
 };
 
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
