@@ -472,6 +472,7 @@ static int PrepareScene(qa_ctx *c)
   ds.light = QA_BLOB_PTR(qa_light, c->dBlob, h->off_lights);
   int rc;
   if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
+  c->hostMeshes = dmeshes;
   if ((rc = DeviceCopy(c, dmat, &ds.mtl)) != QA_OK) return rc;
   // ---- texture-side tables (TEX kernel variants) -------------------------------------------------
   ds.texmap = QA_BLOB_PTR(qa_texmap, c->dBlob, h->off_texmaps);

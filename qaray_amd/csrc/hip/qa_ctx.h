@@ -50,6 +50,7 @@ struct qa_ctx {
   std::vector<unsigned char> hostBlob;
   unsigned char *dBlob = nullptr;
   std::vector<void *> sceneAllocs;  // derived arrays
+  std::vector<DMesh> hostMeshes;    // host copy of the device mesh table
   DScene ds{};
   bool haveScene = false;
   float *dHalton = nullptr;

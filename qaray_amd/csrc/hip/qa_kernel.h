@@ -651,7 +651,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
     bool redo = true;
     const float hz0 = h.z;
-    if (m.useWide && 2.f * (oMax + m.absMax) < m.cancelDist) {
+    if (m.useWide && 1.7321f * (oMax + 2.f * m.absMax) < m.cancelDist) {
       const float pad = m.nearPad + 1e-6f * (oMax + m.absMax);
       hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), tris, m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
       redo = tie;

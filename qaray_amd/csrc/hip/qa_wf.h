@@ -658,8 +658,10 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       // hitSphere / hitPlane update only on a strictly smaller distance: bestK ends as the first instance at h.z
       if (hit) { bestK = k; occluded = !closest; }
     }
-    // ---- meshes: one job per entered bound
+    // ---- meshes: one job per entered bound.  A ray whose origin lies so far from a mesh that the reference's inside test
+    // can accept by cancellation (qa_widebvh.h ComputeMeshSlack) cannot be searched with a pruned walk: it goes to wf_redo.
     unsigned njobs = 0;
+    bool exact = false;
     for (int k = 1; k < sc.num_inst; ++k) {
       if (sc.inst[k].obj_type != QA_OBJ_MESH) continue;
       const DMesh &m = sc.mesh[sc.inst[k].mesh];
@@ -667,7 +669,11 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       const Ray r = localRay<false>(sc, k, r0);
       float entry, exit_;
       wfMeshGate(m, r, entry, exit_);
-      const bool go = valid && !occluded && !(entry > h.z || entry > exit_);
+      bool go = valid && !occluded && !exact && !(entry > h.z || entry > exit_);
+      if (go) {
+        const float oMax = qmax(qmax(qabs(r.p.x), qabs(r.p.y)), qabs(r.p.z));
+        if (!(1.7321f * (oMax + 2.f * m.absMax) < m.cancelDist)) { exact = true; go = false; }
+      }
       const unsigned long long mask = __ballot(go);
       if (!mask) continue;
       const uint32_t n = (uint32_t) __popcll(mask);
@@ -685,6 +691,7 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       if (closest) b.key[slot] = bestK < 0 ? ~0ull : wfKey(h.z, bestK, 0);
       else if (occluded) atomicAnd(&b.vis[slot], ~(1u << j));
       if (njobs) atomicAdd(&b.out[slot], njobs);
+      if (exact) atomicOr(&b.redoFlag[slot], 1u << (closest ? 0u : j + 1u));
     }
   }
   flush();
@@ -693,15 +700,20 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
 // ---------------------------------------------------------------------------------------------
 // wf_trace: persistent waves, one BVH walk (job) per lane, finished lanes refilled from the queue.
 //
+// The walk searches the library's 4-wide tree over the reference tree's leaves (qa_widebvh.h, walkWide of
+// qa_kernel.h cut into rounds): boxes widened by the fp32 slack of the reference's inside test, non-strict tests,
+// nearest child first; leaves are the reference's own, their triangles tested with the reference's arithmetic.
 // A lane is walking (at an inner node or at a leaf), finished, over its step budget, or idle.  Each round the
-// wave runs the body more of its lanes wait for (node step: one 64-byte sibling pair + two slab tests; leaf
-// step: the leaf's triangles), so both bodies execute with most lanes enabled.  Once a quarter of the wave is
-// not walking, the finished lanes commit (one 64-bit atomicMin of (distance, instance, triangle) per closest
-// job, one atomicAnd per shadow hit), the over-budget lanes write their job back with its stack (it continues
-// in the next pass: a pass never waits for the ray that grazes a gridded wall for ten thousand steps), and
-// all of them take new jobs from a range of the queue the wave has reserved with one atomic per 256 jobs.
-// The walk is TriObj::TraceBVHNode's (src/objects/objects.cpp:324-420): near child first, far child stacked,
-// strict tests, a leaf's triangles in element order.  Dynamic LDS: the lanes' traversal stacks.
+// wave runs the body more of its lanes wait for (node step: one 128-byte node, four slab tests; leaf step: the
+// leaf's triangles), so both bodies execute with most lanes enabled.  Once a quarter of the wave is not
+// walking, the finished lanes commit (closest: one 64-bit atomicMin of (distance, instance, triangle); shadow:
+// one atomicAnd), the over-budget lanes write their job back with its stack (it continues in the next pass: a
+// pass never waits for the ray that grazes a gridded wall for thousands of steps), and all of them take new
+// jobs from a range of the queue the wave has reserved with one atomic per 256 jobs.
+// What makes the answers the reference's: wf_logic's order check of the winning hit (wfHitDetails); here, a tie
+// (a second triangle passing the inside test at exactly the held distance), a full stack, and a shadow hit
+// whose reference leaf fails the strict test against the ray's t_max all send the ray to wf_redo.
+// Dynamic LDS: the lanes' traversal stacks.
 // ---------------------------------------------------------------------------------------------
 #ifndef QA_WF_TRACE_WAVES
 #define QA_WF_TRACE_WAVES 5
@@ -713,36 +725,47 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
                                                                           uint32_t budget)
 {
   extern __shared__ uint4 s_dyn[];
-  __shared__ unsigned long long s_nodes[32], s_tris[32];
+  __shared__ unsigned long long s_wnodes[32], s_tris[32], s_nodes[32], s_shade[32];
   __shared__ uint32_t s_root[32];
+  __shared__ float s_pad[32], s_absMax[32];
   if (threadIdx.x < 32) {
     const int k = (int) threadIdx.x;
-    unsigned long long nd = 0, tr = 0;
+    unsigned long long wn = 0, tr = 0, nd = 0, sh = 0;
     uint32_t root = QA_DONE;
+    float pad = 0.f, am = 0.f;
     if (k < sc.num_inst && sc.inst[k].obj_type == QA_OBJ_MESH) {
       const DMesh &m = sc.mesh[sc.inst[k].mesh];
-      nd = (unsigned long long) m.nodes;
+      wn = (unsigned long long) m.wnodes;
       tr = (unsigned long long) m.tris;
-      root = m.rootData;
+      nd = (unsigned long long) m.nodes;
+      sh = (unsigned long long) m.shade;
+      root = m.wrootWord;
+      pad = m.nearPad;
+      am = m.absMax;
     }
-    s_nodes[k] = nd;
+    s_wnodes[k] = wn;
     s_tris[k] = tr;
+    s_nodes[k] = nd;
+    s_shade[k] = sh;
     s_root[k] = root;
+    s_pad[k] = pad;
+    s_absMax[k] = am;
   }
   __syncthreads();
   uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn) + threadIdx.x;   // entry s at stack[s * QA_BLOCK]
+  const uint32_t cap = b.stackDepth;
   const unsigned lane = __lane_id();
   const unsigned nCont = min(b.contCount[parity], b.contCap), nNew = min(ctr->nJobs, b.jobCap);
   const unsigned total = nCont + nNew;
+  const float INF = __builtin_inff();
 
-  bool have = false, over = false, exhausted = false;
+  bool have = false, over = false, exhausted = false, tie = false;
   f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), drcp = F3(0, 0, 1);
-  float hz = 0.f;
+  float hz = 0.f, hz0 = 0.f, pad = 0.f;
   uint32_t bits = 0, best = QA_WF_NOBEST, cur = QA_DONE, sp = 0, steps = 0;
-  bool nearZero = false;
-  const uint4 *nodes = nullptr, *tris = nullptr;
+  const uint4 *wn = nullptr, *tris = nullptr;
   uint32_t rNext = 0, rEnd = 0;                       // the wave's reserved range of job indices (wave-uniform)
-  uint32_t nNode = 0, nLeaf = 0, nTri = 0, nJobsDone = 0, nSusp = 0;
+  uint32_t nNode = 0, nLeaf = 0, nTri = 0, nJobsDone = 0, nSusp = 0, nFlag = 0;
   unsigned long long nSlots = 0, nRounds = 0;
 
   for (;;) {
@@ -754,10 +777,22 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
       // ---- finished jobs commit
       if (have && cur == QA_DONE) {
         const unsigned slot = bits & QA_WF_SLOT_MASK, type = (bits >> 24) & 7u, k = bits >> 27;
-        if (best != QA_WF_NOBEST) {
+        bool flag = tie;
+        if (best != QA_WF_NOBEST && !flag) {
           if (type == 0) atomicMin(&b.key[slot], wfKey(hz, (int) k, best));
-          else atomicAnd(&b.vis[slot], ~(1u << (type - 1u)));
+          else {
+            // the reference reports "occluded" iff it reaches an accepted triangle: this one's leaf must pass its strict
+            // test against the ray's fixed t_max (refReaches); if it does not, only the exact walk can tell
+            Ray ray;
+            ray.p = lo;
+            ray.d = ld;
+            const uint32_t leaf = reinterpret_cast<const uint4 *>(s_shade[k])[3 * (size_t) best + 2].w;
+            const bool nearZero = qabs(ld.x) < 1e-7f || qabs(ld.y) < 1e-7f || qabs(ld.z) < 1e-7f;
+            if (refReaches(reinterpret_cast<const uint4 *>(s_nodes[k]), leaf, ray, drcp, !nearZero, hz0)) atomicAnd(&b.vis[slot], ~(1u << (type - 1u)));
+            else flag = true;
+          }
         }
+        if (flag) { atomicOr(&b.redoFlag[slot], 1u << type); ++nFlag; }
         atomicSub(&b.out[slot], 1u);   // read by the next pass's wf_logic: ordered by the kernel boundary
         have = false;
         ++nJobsDone;
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
           if (at < b.contCap) {
             b.contA[parity ^ 1u][at] = make_float4(lo.x, lo.y, lo.z, hz);
             b.contB[parity ^ 1u][at] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(bits));
-            b.contC[parity ^ 1u][at] = make_uint4(best, cur, sp, 0);
+            b.contC[parity ^ 1u][at] = make_uint4(best, cur, sp | (tie ? 0x80000000u : 0u), __float_as_uint(hz0));
             uint32_t *sv = b.contStack[parity ^ 1u] + (size_t) at * b.stackDepth;
             for (uint32_t q = 0; q < sp; ++q) sv[q] = stack[q * QA_BLOCK];
             have = false;
@@ -806,7 +841,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
             const uint4 C = b.contC[parity][my];
             best = C.x;
             cur = C.y;
-            sp = C.z;
+            sp = C.z & 0x7FFFFFFFu;
+            tie = (C.z >> 31) != 0;
+            hz0 = __uint_as_float(C.w);
             const uint32_t *sv = b.contStack[parity] + (size_t) my * b.stackDepth;
             for (uint32_t q = 0; q < sp; ++q) stack[q * QA_BLOCK] = sv[q];
           } else {
@@ -814,16 +851,18 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
             B = b.jobB[my - nCont];
             best = QA_WF_NOBEST;
             sp = 0;
+            tie = false;
+            hz0 = A.w;
           }
           lo = F3(A.x, A.y, A.z);
           hz = A.w;
           ld = F3(B.x, B.y, B.z);
           bits = __float_as_uint(B.w);
           drcp = F3(1.f / ld.x, 1.f / ld.y, 1.f / ld.z);
-          nearZero = qabs(ld.x) < 1e-7f || qabs(ld.y) < 1e-7f || qabs(ld.z) < 1e-7f;
           const uint32_t k = bits >> 27;
-          nodes = reinterpret_cast<const uint4 *>(s_nodes[k]);
+          wn = reinterpret_cast<const uint4 *>(s_wnodes[k]);
           tris = reinterpret_cast<const uint4 *>(s_tris[k]);
+          pad = s_pad[k] + 1e-6f * (qmax(qmax(qabs(lo.x), qabs(lo.y)), qabs(lo.z)) + s_absMax[k]);
           if (my >= nCont) cur = s_root[k];
           steps = 0;
           over = false;
@@ -838,33 +877,45 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     const bool atInner = have && !over && !(cur & QA_BVH_LEAF_BIT);
     const bool atLeaf = have && !over && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE;
     const int nI = __popcll(__ballot(atInner)), nL = __popcll(__ballot(atLeaf));
-    Ray ray;
-    ray.p = lo;
-    ray.d = ld;
     if (nI >= nL && nI > 0) {
-      const bool fastSlab = !__any(atInner && nearZero);
       if (atInner) {
-        const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
-        const uint4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
-        float entry0, exit0, entry1, exit1;
-        const f3 min0 = F3(asF(a0.x), asF(a0.y), asF(a0.z)), max0 = F3(asF(a0.w), asF(a1.x), asF(a1.y));
-        const f3 min1 = F3(asF(b0.x), asF(b0.y), asF(b0.z)), max1 = F3(asF(b0.w), asF(b1.x), asF(b1.y));
-        if (fastSlab) {
-          boxEntryExitFast(ray, drcp, min0, max0, entry0, exit0);
-          boxEntryExitFast(ray, drcp, min1, max1, entry1, exit1);
-        } else {
-          boxEntryExit(ray, drcp, min0, max0, entry0, exit0);
-          boxEntryExit(ray, drcp, min1, max1, entry1, exit1);
+        const f3 pLo = lo + F3(pad, pad, pad), pHi = lo - F3(pad, pad, pad);
+        const uint4 *nd = wn + 8 * (size_t) cur;
+        const uint4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hzz = nd[5], ch = nd[6];
+        float k0, k1, k2, k3;
+        uint32_t w0 = ch.x, w1 = ch.y, w2 = ch.z, w3 = ch.w;
+#define QA_WIDE_CHILD(K, W, LX, LY, LZ, HX, HY, HZ)                                                                           \
+        {                                                                                                                      \
+          const f3 p0 = (F3(asF(LX), asF(LY), asF(LZ)) - pLo) * drcp, p1 = (F3(asF(HX), asF(HY), asF(HZ)) - pHi) * drcp;      \
+          const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z)); \
+          const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z)); \
+          K = (W != QA_DONE && en <= hz && en <= ex) ? en : INF;                                                               \
         }
-        const bool hit0 = entry0 < hz && entry0 < exit0;
-        const bool hit1 = entry1 < hz && entry1 < exit1;
-        const uint32_t d0 = a1.z, d1 = b1.z;
-        if (hit0 && hit1) {
-          const bool nearFirst = entry0 < entry1;
-          stack[(sp++) * QA_BLOCK] = nearFirst ? d1 : d0;
-          cur = nearFirst ? d0 : d1;
-        } else if (hit0) cur = d0;
-        else if (hit1) cur = d1;
+        QA_WIDE_CHILD(k0, w0, lx.x, ly.x, lz.x, hx.x, hy.x, hzz.x)
+        QA_WIDE_CHILD(k1, w1, lx.y, ly.y, lz.y, hx.y, hy.y, hzz.y)
+        QA_WIDE_CHILD(k2, w2, lx.z, ly.z, lz.z, hx.z, hy.z, hzz.z)
+        QA_WIDE_CHILD(k3, w3, lx.w, ly.w, lz.w, hx.w, hy.w, hzz.w)
+#undef QA_WIDE_CHILD
+#define QA_WIDE_CE(KA, WA, KB, WB)                                  \
+        {                                                           \
+          const bool sw = KA > KB;                                  \
+          const float tk = sw ? KB : KA;                            \
+          KB = sw ? KA : KB;                                        \
+          KA = tk;                                                  \
+          const uint32_t tw = sw ? WB : WA;                         \
+          WB = sw ? WA : WB;                                        \
+          WA = tw;                                                  \
+        }
+        QA_WIDE_CE(k0, w0, k1, w1)
+        QA_WIDE_CE(k2, w2, k3, w3)
+        QA_WIDE_CE(k0, w0, k2, w2)
+        QA_WIDE_CE(k1, w1, k3, w3)
+        QA_WIDE_CE(k1, w1, k2, w2)
+#undef QA_WIDE_CE
+        if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
+        if (k2 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w2; else tie = true; }
+        if (k1 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w1; else tie = true; }
+        if (k0 < INF) cur = w0;
         else cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
         ++steps;
         ++nNode;
@@ -873,6 +924,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
       ++nRounds;
     } else if (nL > 0) {
       if (atLeaf) {
+        Ray ray;
+        ray.p = lo;
+        ray.d = ld;
         const uint32_t count = ((cur >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
         const uint32_t first = cur & QA_BVH_OFFSET_MASK;
         const bool anyHit = ((bits >> 24) & 7u) != 0;
@@ -880,7 +934,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
         for (uint32_t i = 0; i < count && !stop; ++i) {
           const uint4 *t = tris + 3 * (size_t) (first + i);
           ++nTri;
-          if (hitTriangleZ(t[0], t[1], t[2], ray, hz)) {
+          if (hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie)) {
             best = first + i;
             stop = anyHit;                  // TraceNodeShadow: the first accepted triangle ends the query
           }
@@ -896,7 +950,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
   }
 
   // ---- statistics: one atomic per wave and counter
-  unsigned long long v[8] = {nJobsDone, nNode, nLeaf, nTri, 0, nSusp, nSlots, nRounds};
+  unsigned long long v[8] = {nJobsDone, nNode, nLeaf, nTri, nFlag, nSusp, nSlots, nRounds};
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(b.stats);
   for (int i = 0; i < 8; ++i) {
     unsigned long long x = v[i];

@@ -118,6 +118,8 @@ void SelectStaged(qa_ctx *c)
     }
   }
   ok = ok && anyMesh;
+  // the trace stage searches the 4-wide trees only (qa_widebvh.h)
+  for (const DMesh &dm : c->hostMeshes) if (dm.num_faces > 0 && !dm.useWide) ok = false;
   if (const char *e = getenv("QA_PIPELINE")) {
     if (!strcmp(e, "mega")) ok = false;
   }

@@ -228,8 +228,11 @@ class WideBvhBuilder {
 //            by <= 8 eps (L + d)^2 / (2 A), i.e. a point up to 8 eps L^2 / |edge| outside an edge passes; three edges,
 //            the third barycentric is a difference of the other two, and the dropped axis shortens in-plane lengths by
 //            at most sqrt(3): 48 eps L^2 / (shortest projected edge), maximised over the triangles.
-//   cancelDist: from about |edge| / (8 eps) away the areas cancel and the test is no longer geometric; rays whose
-//            origin is not well inside that distance (a quarter of it) keep the reference tree.
+//   cancelDist: a point farther than |edge| / (8 eps) - 2 L from a triangle can pass the test by cancellation of the
+//            areas.  That matters to a pruned search only when such a "hit" lies BEFORE the triangle's leaf box on the
+//            ray, i.e. between the origin and the mesh: no farther from the triangle than sqrt(3) (|origin| + 2 |mesh|)
+//            (largest coordinates).  Rays for which that reach is not below half the smallest cancellation distance
+//            of the mesh keep the reference tree (hitMesh).
 // Degenerate triangles (NaN normal: never accepted) are left out.
 struct MeshSlack { float nearPad, cancelDist; };
 inline MeshSlack ComputeMeshSlack(const DTri *tris, uint32_t n, const float *vertsOfElement /* 9 floats per element */)
@@ -251,7 +254,7 @@ inline MeshSlack ComputeMeshSlack(const DTri *tris, uint32_t n, const float *ver
     }
     if (!(e2 > 0) || !(L > 0)) { cancel = 0; continue; }
     pad = std::max(pad, 48.0 * eps * L * L / e2);
-    cancel = std::min(cancel, 0.25 * e2 / (8.0 * eps));
+    cancel = std::min(cancel, 0.5 * (e2 / (8.0 * eps) - 2.0 * L));
   }
   MeshSlack s;
   s.nearPad = (float) std::min(pad * 1.0000001 + 1e-30, 1e30);
