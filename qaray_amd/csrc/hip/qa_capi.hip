@@ -61,6 +61,23 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
   return stats ? PickShading<false, true>(lights, tex, area) : PickShading<false, false>(lights, tex, area);
 }
 
+static void SetKernelName(qa_ctx *c)
+{
+  char name[160];
+  snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured,
+           (int) c->area);
+  const WfHost &w = c->wf;
+  const char *staged = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
+  if (!w.eligible || w.mode == 0) c->kernelName = name;
+  else if (w.mode == 1) c->kernelName = staged;
+  else if (w.decision < 0) c->kernelName = std::string(name) + " (staged integrator eligible: decided by a timed probe at the first large frame)";
+  else {
+    char buf[96];
+    snprintf(buf, sizeof(buf), " (probe: megakernel %.2f ms, staged %.2f ms)", w.probeMs[0], w.probeMs[1]);
+    c->kernelName = std::string(w.decision == 1 ? staged : name) + buf;
+  }
+}
+
 // Choose the kernel variant for the uploaded scene and size the persistent grid to what is
 // resident at once (VGPR / LDS-limited workgroups per CU x CUs).
 static int SelectKernel(qa_ctx *c)
@@ -72,9 +89,7 @@ static int SelectKernel(qa_ctx *c)
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
-  char name[160];
-  snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) lights, (int) c->textured, (int) c->area);
-  c->kernelName = c->wf.eligible ? "staged: wf_logic + wf_cull + wf_trace + wf_redo" : name;
+  SetKernelName(c);
   return QA_OK;
 }
 
@@ -393,6 +408,7 @@ static int PrepareScene(qa_ctx *c)
     }
     dm.stackNeed = stackNeed;
     dm.wrootWord = allWide[mi].rootWord;
+    dm.wideStack = 3 * allWide[mi].depth + 2;
     dm.nearPad = meshSlack[mi].nearPad;
     dm.cancelDist = meshSlack[mi].cancelDist;
     {
@@ -661,13 +677,52 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
+  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on a
+  // 4-spp frame of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
+  // the megakernel where shading does) and keeps the answer until the next scene upload.
+  bool staged = false;
+  if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
+    WfHost &w = c->wf;
+    if (w.mode == 1) staged = true;
+    else if (w.mode == 2) {
+      const size_t pixels = (size_t) tiles * 64;
+      if (w.decision < 0 && spp_min == spp_max && spp_max >= 64 && pixels >= 500000 && !pmOn) {
+        RenderParams pr = rp;
+        pr.spp_min = pr.spp_max = 4;
+        pr.counters = c->dCountersProbe;
+        hipEvent_t e0, e1, e2;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+        HIP_TRY(hipEventRecord(e0, s));
+        rc = RenderStaged(c, ds, pr, s, c->dCountersProbe);
+        if (rc != QA_OK) return rc;
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, pr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e2, s));
+        HIP_TRY(hipEventSynchronize(e2));
+        float msStaged = 0, msMega = 0;
+        HIP_TRY(hipEventElapsedTime(&msStaged, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&msMega, e1, e2));
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipEventDestroy(e2);
+        w.decision = msStaged < msMega ? 1 : 0;
+        w.probeMs[0] = msMega;
+        w.probeMs[1] = msStaged;
+        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
+        SetKernelName(c);
+      }
+      staged = w.decision == 1;
+    }
+  }
+
   EventPair ev;
   if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
   else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
   HIP_TRY(hipEventRecord(ev.a, s));
-  if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
-    // scenes whose geometry does not fit LDS: the staged integrator (qa_wf.h), one event pair around the frame
-    rc = RenderStaged(c, ds, rp, s);
+  if (staged) {
+    // one event pair around the whole frame of the staged integrator (qa_wf.h)
+    rc = RenderStaged(c, ds, rp, s, c->dCounters);
     if (rc != QA_OK) { c->freeEvents.push_back(ev); return rc; }
   } else {
     hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
@@ -782,13 +837,15 @@ int qa_ctx_create(int device_id, qa_ctx **out)
       (e = hipMalloc((void **) &c->dWork, qa_ctx::kCounterRing * sizeof(unsigned int))) != hipSuccess ||
       (e = hipMalloc((void **) &c->dCounters, sizeof(DCounters))) != hipSuccess ||
       (e = hipMemset(c->dCounters, 0, sizeof(DCounters))) != hipSuccess ||
+      (e = hipMalloc((void **) &c->dCountersProbe, sizeof(DCounters))) != hipSuccess ||
       (e = hipHostMalloc((void **) &c->hStop, sizeof(int), hipHostMallocMapped)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
   }
   *c->hStop = 0;
   if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
-  if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 128u;
+  if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
+  if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
   if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
@@ -811,6 +868,7 @@ int qa_ctx_destroy(qa_ctx *c)
   if (c->dOrder) (void) hipFree(c->dOrder);
   if (c->dWork) (void) hipFree(c->dWork);
   if (c->dCounters) (void) hipFree(c->dCounters);
+  if (c->dCountersProbe) (void) hipFree(c->dCountersProbe);
   if (c->hStop) (void) hipHostFree(c->hStop);
   if (c->dRgb) (void) hipFree(c->dRgb);
   if (c->dDepth) (void) hipFree(c->dDepth);
@@ -962,6 +1020,17 @@ int qa_get_staged_stats(qa_ctx *c, uint64_t out[QA_STAGED_STATS])
   const uint64_t v[QA_STAGED_STATS] = {c->wf.iterations, c->wf.raysClosest, c->wf.raysShadow, c->wf.jobs, c->wf.redo, st.jobs, st.nodeSteps,
                                        st.leafSteps, st.triTests, st.redo, st.suspended, st.laneSlots, st.waveRounds};
   memcpy(out, v, sizeof(v));
+  return QA_OK;
+}
+
+int qa_set_pipeline(qa_ctx *c, int mode)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  if (mode < QA_PIPE_MEGA || mode > QA_PIPE_AUTO) return Fail(QA_EINVAL, "pipeline mode must be QA_PIPE_MEGA, QA_PIPE_STAGED or QA_PIPE_AUTO");
+  c->wf.mode = mode;
+  c->wf.modeSet = true;
+  c->wf.decision = -1;
+  if (c->haveScene) SetKernelName(c);
   return QA_OK;
 }
 

@@ -28,6 +28,10 @@ struct EventPair { hipEvent_t a, b; };
 // Host side of the staged integrator (qa_wf.hip): buffers are kept between frames
 struct WfHost {
   bool eligible = false;        // the uploaded scene can run staged (SelectStaged)
+  bool modeSet = false;         // qa_set_pipeline was called
+  int mode = 2;                 // QA_PIPELINE: 0 mega, 1 staged, 2 auto (timed probe at the first large frame)
+  int decision = -1;            // auto: -1 not probed yet, 0 megakernel, 1 staged
+  float probeMs[2] = {0.f, 0.f};
   int numLights = 0;            // non-ambient lights
   int32_t lightIdx[QA_WF_MAX_LIGHTS] = {0, 0, 0, 0};
   WfBuf buf{};
@@ -39,7 +43,8 @@ struct WfHost {
   // diagnostics of the frames rendered since the last reset
   uint64_t iterations = 0, raysClosest = 0, raysShadow = 0, jobs = 0, redo = 0;
   int traceBlocksPerCU = 0;     // 0 = ask the occupancy API at the first frame
-  uint32_t budget = 128;        // BVH steps a job may take per pass (QA_WF_BUDGET)
+  uint32_t stackCap = 24;       // LDS stack entries per lane of wf_trace (QA_WF_STACK)
+  uint32_t budget = 512;        // BVH steps a job may take per pass (QA_WF_BUDGET)
 };
 
 struct qa_ctx {
@@ -61,7 +66,7 @@ struct qa_ctx {
   int workNext = 0;
   int *hStop = nullptr;           // mapped host memory, read by the kernel's wave leaders
   int *dStopAlias = nullptr;
-  DCounters *dCounters = nullptr;
+  DCounters *dCounters = nullptr, *dCountersProbe = nullptr;
   // host-variant staging
   float *dRgb = nullptr, *dDepth = nullptr;
   uint32_t *dNs = nullptr;
@@ -101,7 +106,7 @@ void FreePhotonMaps(qa_ctx *c);  // qa_photon.hip
 void FreeStaged(qa_ctx *c);
 void SelectStaged(qa_ctx *c);
 bool StagedTakes(const qa_ctx *c, uint32_t flags, int spp_max, int max_bounce, size_t slots);
-int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_t s);
+int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_t s, DCounters *frameCounters);
 
 inline void FreeScene(qa_ctx *c)
 {

@@ -583,6 +583,20 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
   return hasHit;
 }
 
+// May this ray be searched with a pruned walk of mesh m?  The reference's inside test can accept, by cancellation of
+// its 2-D areas, a point farther than DMesh::cancelDist (qa_widebvh.h ComputeMeshSlack) from a triangle.  A pruned
+// search goes wrong only if such a "hit" lies before the triangle's leaf box on the ray, i.e. on the segment from the
+// origin to the mesh bounds - which is never farther from any triangle than the origin's farthest corner of the
+// bounds, or the bounds' diagonal.
+__device__ __forceinline__ bool insideCancelReach(const DMesh &m, f3 o)
+{
+  const f3 bmin = ld3(m.bmin), bmax = ld3(m.bmax);
+  const f3 f = F3(qmax(qabs(o.x - bmin.x), qabs(o.x - bmax.x)), qmax(qabs(o.y - bmin.y), qabs(o.y - bmax.y)), qmax(qabs(o.z - bmin.z), qabs(o.z - bmax.z)));
+  const f3 dg = bmax - bmin;
+  const float reach2 = qmax(dot(f, f), dot(dg, dg));
+  return reach2 * 1.0001f < m.cancelDist * m.cancelDist;
+}
+
 // Would the reference's walk have reached the leaf `leaf` of its tree?  It enters a node when the
 // strict box test passes against the distance held at that moment.  Every inner box of the tree is
 // the union of its children's boxes (min / max of the same floats), and the slab arithmetic is
@@ -651,7 +665,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
     bool redo = true;
     const float hz0 = h.z;
-    if (m.useWide && 1.7321f * (oMax + 2.f * m.absMax) < m.cancelDist) {
+    if (m.useWide && insideCancelReach(m, ray.p)) {
       const float pad = m.nearPad + 1e-6f * (oMax + m.absMax);
       hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), tris, m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
       redo = tie;

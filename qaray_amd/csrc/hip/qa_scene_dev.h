@@ -103,6 +103,7 @@ struct DMesh {
   const DWideNode *wnodes;
   uint32_t wrootWord;          // child word of the root
   uint32_t useWide;
+  uint32_t wideStack;          // stack entries a walk of the wide tree can need (3 per level + 2)
   float nearPad;               // fp32 slack of the reference's inside test (qa_widebvh.h ComputeMeshSlack)
   float cancelDist;            // ray origins farther out than this keep the reference tree
 };

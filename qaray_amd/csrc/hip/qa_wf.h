@@ -670,10 +670,7 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       float entry, exit_;
       wfMeshGate(m, r, entry, exit_);
       bool go = valid && !occluded && !exact && !(entry > h.z || entry > exit_);
-      if (go) {
-        const float oMax = qmax(qmax(qabs(r.p.x), qabs(r.p.y)), qabs(r.p.z));
-        if (!(1.7321f * (oMax + 2.f * m.absMax) < m.cancelDist)) { exact = true; go = false; }
-      }
+      if (go && !insideCancelReach(m, r.p)) { exact = true; go = false; }
       const unsigned long long mask = __ballot(go);
       if (!mask) continue;
       const uint32_t n = (uint32_t) __popcll(mask);
@@ -753,7 +750,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
   }
   __syncthreads();
   uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn) + threadIdx.x;   // entry s at stack[s * QA_BLOCK]
-  const uint32_t cap = b.stackDepth;
+  const uint32_t cap = b.traceStack;
   const unsigned lane = __lane_id();
   const unsigned nCont = min(b.contCount[parity], b.contCap), nNew = min(ctr->nJobs, b.jobCap);
   const unsigned total = nCont + nNew;
@@ -773,7 +770,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     const unsigned long long mFin = __ballot(have && (cur == QA_DONE || over));
     const int nWalk = __popcll(mWalk);
     const bool canRefill = !exhausted || rNext < rEnd;
-    if ((64 - nWalk >= 16 && (mFin || canRefill)) || (nWalk == 0)) {
+    if ((64 - nWalk >= (int) b.refillAt && (mFin || canRefill)) || (nWalk == 0)) {
       // ---- finished jobs commit
       if (have && cur == QA_DONE) {
         const unsigned slot = bits & QA_WF_SLOT_MASK, type = (bits >> 24) & 7u, k = bits >> 27;
@@ -810,7 +807,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
             b.contA[parity ^ 1u][at] = make_float4(lo.x, lo.y, lo.z, hz);
             b.contB[parity ^ 1u][at] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(bits));
             b.contC[parity ^ 1u][at] = make_uint4(best, cur, sp | (tie ? 0x80000000u : 0u), __float_as_uint(hz0));
-            uint32_t *sv = b.contStack[parity ^ 1u] + (size_t) at * b.stackDepth;
+            uint32_t *sv = b.contStack[parity ^ 1u] + (size_t) at * b.traceStack;
             for (uint32_t q = 0; q < sp; ++q) sv[q] = stack[q * QA_BLOCK];
             have = false;
             ++nSusp;
@@ -844,7 +841,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
             sp = C.z & 0x7FFFFFFFu;
             tie = (C.z >> 31) != 0;
             hz0 = __uint_as_float(C.w);
-            const uint32_t *sv = b.contStack[parity] + (size_t) my * b.stackDepth;
+            const uint32_t *sv = b.contStack[parity] + (size_t) my * b.traceStack;
             for (uint32_t q = 0; q < sp; ++q) stack[q * QA_BLOCK] = sv[q];
           } else {
             A = b.jobA[my - nCont];

@@ -36,7 +36,7 @@ int Alloc(WfHost &w, T **out, size_t count)
   return QA_OK;
 }
 
-int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth)
+int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth, uint32_t traceStack)
 {
   WfHost &w = c->wf;
   if (!w.dCtr) {
@@ -45,7 +45,7 @@ int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth)
     HIP_TRY(hipMemset(w.dStats, 0, sizeof(WfStats)));
     HIP_TRY(hipHostMalloc((void **) &w.hCtr, kChunk * sizeof(WfCounters), hipHostMallocDefault));
   }
-  if (slots <= w.capSlots && lights == w.capLights && stackDepth == w.buf.stackDepth) return QA_OK;
+  if (slots <= w.capSlots && lights == w.capLights && stackDepth == w.buf.stackDepth && traceStack == w.buf.traceStack) return QA_OK;
   FreeBuffers(w);
   WfBuf &b = w.buf;
   int rc;
@@ -62,10 +62,11 @@ int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth)
   b.jobCap = (uint32_t) std::min<size_t>(slots * (1 + nl) * 2, 0x7FFFFFFFu);
   b.contCap = (uint32_t) std::max<size_t>(b.jobCap / 4, 4096);
   b.stackDepth = stackDepth;
+  b.traceStack = traceStack;
   if ((rc = Alloc(w, &b.jobA, b.jobCap)) || (rc = Alloc(w, &b.jobB, b.jobCap))) { FreeBuffers(w); return rc; }
   for (int k = 0; k < 2; ++k)
     if ((rc = Alloc(w, &b.contA[k], b.contCap)) || (rc = Alloc(w, &b.contB[k], b.contCap)) || (rc = Alloc(w, &b.contC[k], b.contCap)) ||
-        (rc = Alloc(w, &b.contStack[k], (size_t) b.contCap * stackDepth))) { FreeBuffers(w); return rc; }
+        (rc = Alloc(w, &b.contStack[k], (size_t) b.contCap * traceStack))) { FreeBuffers(w); return rc; }
   b.stats = w.dStats;
   w.capSlots = slots;
   w.capLights = lights;
@@ -120,9 +121,14 @@ void SelectStaged(qa_ctx *c)
   ok = ok && anyMesh;
   // the trace stage searches the 4-wide trees only (qa_widebvh.h)
   for (const DMesh &dm : c->hostMeshes) if (dm.num_faces > 0 && !dm.useWide) ok = false;
-  if (const char *e = getenv("QA_PIPELINE")) {
-    if (!strcmp(e, "mega")) ok = false;
+  if (!w.modeSet) {     // qa_set_pipeline outlives scene uploads; otherwise the environment decides
+    w.mode = QA_PIPE_AUTO;
+    if (const char *e = getenv("QA_PIPELINE")) {
+      if (!strcmp(e, "mega")) w.mode = QA_PIPE_MEGA;
+      else if (!strcmp(e, "staged")) w.mode = QA_PIPE_STAGED;
+    }
   }
+  w.decision = -1;
   w.eligible = ok;
   w.numLights = ok ? nl : 0;
 }
@@ -133,13 +139,18 @@ bool StagedTakes(const qa_ctx *c, uint32_t flags, int spp_max, int max_bounce, s
          slots <= ((size_t) 1 << QA_WF_SLOT_BITS);
 }
 
-int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_t s)
+int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_t s, DCounters *frameCounters)
 {
   WfHost &w = c->wf;
   const int rw = rp.x1 - rp.x0;
   const size_t tilesX = (size_t) (rw + 7) / 8;
   const size_t slots = tilesX * (size_t) rp.own_tile_rows * 64;
-  int rc = EnsureBuffers(c, slots, w.numLights, ds.stackDepth);
+  // wf_trace's stacks: what the wide trees can need, capped (QA_WF_STACK, default 24): nearest-first walks rarely hold
+  // more than a dozen entries, and every LDS kilobyte saved is occupancy; a full stack sends the ray to wf_redo
+  uint32_t wideNeed = 2;
+  for (const DMesh &dm : c->hostMeshes) if (dm.useWide) wideNeed = std::max(wideNeed, dm.wideStack);
+  const uint32_t traceStack = std::min(wideNeed, w.stackCap);
+  int rc = EnsureBuffers(c, slots, w.numLights, ds.stackDepth, traceStack);
   if (rc != QA_OK) return rc;
   WfBuf b = w.buf;
   b.n = (uint32_t) slots;
@@ -150,9 +161,10 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
   hipLaunchKernelGGL(wf_init, dim3(blocks), dim3(QA_BLOCK), 0, s, ds, rp, b);
   HIP_TRY(hipGetLastError());
   const size_t stackLds = (size_t) ds.stackDepth * QA_BLOCK * sizeof(uint32_t);
+  const size_t traceLds = (size_t) traceStack * QA_BLOCK * sizeof(uint32_t);
   if (!w.traceBlocksPerCU) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) wf_trace, QA_BLOCK, stackLds) != hipSuccess || n < 1) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) wf_trace, QA_BLOCK, traceLds) != hipSuccess || n < 1) n = 2;
     w.traceBlocksPerCU = std::min(n, 8);
   }
   const size_t rays = slots * (1 + b.numLights);
@@ -161,6 +173,7 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
   const unsigned traceBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * w.traceBlocksPerCU, (rays + QA_BLOCK - 1) / QA_BLOCK);
   const unsigned redoBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * 2, (rays + QA_BLOCK - 1) / QA_BLOCK);
   const uint32_t budget = w.budget;
+  b.refillAt = getenv("QA_WF_REFILL") ? (uint32_t) atoi(getenv("QA_WF_REFILL")) : 16u;
   const bool dbg = getenv("QA_WF_DEBUG") != nullptr;
   b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;   // synchronise and report after every stage
   // every pixel advances by at most one path segment per pass; suspended walks add passes
@@ -168,16 +181,17 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
   long long iter = 0;
   bool finished = false;
   while (!finished && iter < maxIter) {
+    if (__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) break;   // tasking::signal_stop: unfinished pixels keep ns = 0
     HIP_TRY(hipMemsetAsync(w.dCtr, 0, kChunk * sizeof(WfCounters), s));
     for (int i = 0; i < kChunk; ++i, ++iter) {
       WfCounters *ctr = w.dCtr + i;
       const uint32_t parity = (uint32_t) (iter & 1);
-      if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, c->dCounters, parity);
-      else hipLaunchKernelGGL(wf_logic<false>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, c->dCounters, parity);
+      if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, frameCounters, parity);
+      else hipLaunchKernelGGL(wf_logic<false>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, frameCounters, parity);
       if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld logic ok\n", iter); }
       hipLaunchKernelGGL(wf_cull, dim3(cullBlocks), dim3(QA_BLOCK), 0, s, ds, b, ctr);
       if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld cull ok\n", iter); }
-      hipLaunchKernelGGL(wf_trace, dim3(traceBlocks), dim3(QA_BLOCK), (unsigned) stackLds, s, ds, b, ctr, parity, budget);
+      hipLaunchKernelGGL(wf_trace, dim3(traceBlocks), dim3(QA_BLOCK), (unsigned) traceLds, s, ds, b, ctr, parity, budget);
       if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld trace ok\n", iter); }
       hipLaunchKernelGGL(wf_redo, dim3(redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, s, ds, b, ctr);
       if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld redo ok\n", iter); }
@@ -193,7 +207,6 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
       if (w.hCtr[i].active) w.iterations++;
     }
     if (w.hCtr[kChunk - 1].active == 0) finished = true;
-    if (__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) break;   // tasking::signal_stop: unfinished pixels keep ns = 0
   }
   if (!finished && !__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) return Fail(QA_EHIP, "staged integrator did not converge (internal error)");
   return QA_OK;

@@ -78,6 +78,7 @@ def lib():
         L.qa_get_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.qa_reset_kernel_time.argtypes = [C.c_void_p]
         L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.qa_set_pipeline.argtypes = [C.c_void_p, C.c_int]
         L.qa_get_kernel_name.argtypes = [C.c_void_p]
         L.qa_get_kernel_name.restype = C.c_char_p
         L.qa_get_staged_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -222,6 +223,12 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         _check(lib().qa_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    PIPELINES = {"mega": 0, "staged": 1, "auto": 2}
+
+    def set_pipeline(self, mode):
+        """'mega' | 'staged' | 'auto': which integrator renders scenes that do not fit LDS (same bits either way)."""
+        _check(lib().qa_set_pipeline(self._h, self.PIPELINES[mode]))
 
     def kernel_name(self):
         """The integrator the uploaded scene runs on (megakernel variant or the staged pipeline)."""

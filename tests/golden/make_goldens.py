@@ -38,6 +38,12 @@ CASES = [
     ("c3_object_1080p_crop_2spp", "example_project7_object.xml", (1920, 1080), (840, 560, 888, 592), 2, 2, 5),
     ("c4_caustics_4k_crop_4spp", "example_project12_caustics_glossy.xml", (3840, 2160), (1900, 1300, 1948, 1332), 4, 4, 5),
     ("c5_tower_4k_crop_2spp", "trc_scene_tower.xml", (3840, 2160), (1800, 1000, 1848, 1032), 2, 2, 5),
+    # the same configs at the spp BASELINE.json quotes them on (sample indices, Halton rows, RNG stream depth and the
+    # running mean / variance at large n are only exercised there)
+    ("c2_box_1080p_crop_512spp", "example_project12_box.xml", (1920, 1080), (952, 532, 968, 548), 512, 512, 5),
+    ("c3_object_1080p_crop_256spp", "example_project7_object.xml", (1920, 1080), (860, 570, 868, 578), 256, 256, 5),
+    ("c4_caustics_4k_crop_1024spp", "example_project12_caustics_glossy.xml", (3840, 2160), (1920, 1310, 1928, 1318), 1024, 1024, 5),
+    ("c5_tower_4k_crop_2048spp", "trc_scene_tower.xml", (3840, 2160), (1820, 1010, 1828, 1018), 2048, 2048, 5),
 ]
 SEED = 0x51A7A7
 
@@ -56,7 +62,10 @@ def main():
     subprocess.run([sys.executable, os.path.join(SCENES, "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
     if not os.path.exists(HARNESS):
         sys.exit(f"{HARNESS} missing: run `make -C oracle ref` in the dev container")
+    only = set(sys.argv[1:])     # optional: names of the fixtures to (re)generate
     for name, scene, (w, h), crop, smin, smax, bounce in CASES:
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "g")
             cmd = [HARNESS, scene, "--size", str(w), str(h), "--spp-min", str(smin), "--spp-max", str(smax),
@@ -78,6 +87,8 @@ def main():
         print(f"{name}: {cw}x{ch} samples={meta['samples']} casts={meta['casts_normal']}+{meta['casts_shadow']}")
     os.makedirs(os.path.join(HERE, "photon"), exist_ok=True)
     for name, scene, (w, h), spp, pm, cm in PHOTON_CASES:
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "g")
             cmd = [HARNESS, scene, "--size", str(w), str(h), "--spp", str(spp), "--seed", str(SEED), "--threads", "8",

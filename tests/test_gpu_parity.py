@@ -19,11 +19,12 @@ pytestmark = pytest.mark.gpu
 RMSE_TOL = 1e-6
 MAXABS_TOL = 1e-4
 SUPPORTED = ["c1_sphere_256x256_1spp", "c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp",
+             "c2_box_1080p_crop_512spp", "c3_object_1080p_crop_256spp", "c4_caustics_4k_crop_1024spp", "c5_tower_4k_crop_2048spp",
              "blinn_48x36_4spp", "box3_48x36_4spp", "project4_48x36_4spp", "glass_48x36_8spp", "glossy_48x36_8spp",
              "coffee_48x36_4spp_bounce2", "sphere_adaptive_64x48_4to32spp",
              "textures_80x60_2spp", "softshadow_dof_60x45_2spp",
              "c3_object_1080p_crop_2spp", "c4_caustics_4k_crop_4spp", "c5_tower_4k_crop_2spp"]
-BIT_EXACT = ["c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp"]
+BIT_EXACT = ["c2_box_64x64_4spp", "c2_box_1080p_crop_8spp", "c2_box_1080p_edge_crop_64spp", "c2_box_1080p_crop_512spp"]
 
 
 @pytest.fixture(scope="module")

@@ -1,0 +1,289 @@
+"""Scenes whose geometry does not fit LDS (BASELINE C3 / C4 / C5) on a real MI355X: the staged integrator
+(qa_wf.h: logic / cull / trace / redo stages, queues in HBM) and the 4-wide search tree over the reference tree's
+leaves (qa_widebvh.h), each against the reference's goldens, the CPU oracle, the megakernel and the counting
+kernel that walks the reference's cy::BVH exactly as the reference does.
+
+Tolerances: as tests/test_gpu_parity.py (sample counts, first-hit depth, cast counters EXACT; radiance RMSE <= 1e-6,
+max abs <= 1e-4 against the reference).  Between the library's own integrators everything is compared BIT FOR BIT:
+they perform the same arithmetic in the same order and differ only in where the search for the closest hit looks."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits, ensure_assets, golden_blob, load_golden, reference_input_names
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 1e-6
+MAXABS_TOL = 1e-4
+BIG = ["c3_object_1080p_crop_2spp", "c4_caustics_4k_crop_4spp", "c5_tower_4k_crop_2spp"]
+BIG_FULLSPP = ["c3_object_1080p_crop_256spp", "c4_caustics_4k_crop_1024spp", "c5_tower_4k_crop_2048spp"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from qaray_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.set_pipeline("auto")
+    c.close()
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _golden_available(name):
+    from conftest import GOLDEN
+    return os.path.exists(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.mark.parametrize("pipeline", ["staged", "mega"])
+@pytest.mark.parametrize("name", BIG + BIG_FULLSPP)
+def test_big_scene_goldens_on_both_integrators(ctx, name, pipeline):
+    """The reference's own pixels (oracle/_ref) for the three non-resident BASELINE scenes, at 2 - 4 spp and at the
+    spp BASELINE.json quotes them on (256 / 1024 / 2048), through either integrator."""
+    if not _golden_available(name):
+        pytest.skip("golden not generated")
+    rgb, depth, ns, meta = load_golden(name)
+    ctx.set_pipeline(pipeline)
+    ctx.upload_scene(golden_blob(meta))
+    assert ("staged" in ctx.kernel_name()) == (pipeline == "staged")
+    ctx.reset_counters()
+    g_rgb, g_depth, g_ns = ctx.render_region(tuple(meta["crop"]), meta["spp_min"], max_bounce=meta["bounce"], seed=meta["seed"],
+                                             spp_max=meta["spp_max"])
+    cnt = ctx.counters()
+    assert np.array_equal(g_ns, ns)
+    assert np.array_equal(bits(g_depth), bits(depth))
+    assert (cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]) == (meta["samples"], meta["casts_normal"], meta["casts_shadow"])
+    assert rmse(g_rgb, rgb) <= RMSE_TOL
+    assert float(np.abs(g_rgb - rgb).max()) <= MAXABS_TOL
+
+
+@pytest.mark.parametrize("name", reference_input_names())
+def test_every_staged_eligible_reference_input_vs_oracle(ctx, name):
+    """The reference's inputs/*.xml that the staged integrator takes (meshes beyond LDS, no area lights): exact sample
+    counts, depth and cast counters, radiance within the module's tolerances of the CPU oracle."""
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 40, 30, 2
+    blob = load_scene_blob(name, size=(w, h))
+    ctx.set_pipeline("staged")
+    ctx.upload_scene(blob)
+    if "staged" not in ctx.kernel_name():
+        pytest.skip("scene runs on the megakernel (LDS-resident, area lights, ...)")
+    ctx.reset_counters()
+    rgb, depth, ns = ctx.render_region((0, 0, w, h), spp)
+    cnt = ctx.counters()
+    o_rgb, o_depth, o_ns, o_cnt = oracle.render(blob, (0, 0, w, h), spp)
+    assert np.array_equal(ns, o_ns) and np.array_equal(bits(depth), bits(o_depth))
+    assert (cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]) == (o_cnt.samples, o_cnt.casts_normal, o_cnt.casts_shadow)
+    scale = max(1.0, float(np.abs(o_rgb[np.isfinite(o_rgb)]).max()) if np.isfinite(o_rgb).any() else 1.0)
+    assert float(np.nanmax(np.abs(rgb - o_rgb))) <= MAXABS_TOL * scale
+    assert rmse(np.nan_to_num(rgb), np.nan_to_num(o_rgb)) <= RMSE_TOL * scale
+
+
+@pytest.mark.parametrize("scene,size,spp", [("example_project7_object.xml", (480, 270), 8), ("example_project12_caustics_glossy.xml", (480, 270), 8),
+                                            ("trc_scene_tower.xml", (480, 270), 8), ("trc_scene_xmas.xml", (320, 180), 4)])
+def test_staged_megakernel_and_reference_walk_agree_bitwise(ctx, scene, size, spp):
+    """10^6..10^7 casts per scene: the staged integrator, the megakernel on the 4-wide tree and the counting kernel
+    (the reference's binary tree, walked as the reference walks it) return the same bits and the same cast counts.
+    Adaptive sampling included (the sample count of a pixel depends on every radiance bit before it)."""
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h = size
+    ctx.upload_scene(load_scene_blob(scene, size=size))
+    outs, cnts = {}, {}
+    for mode in ("staged", "mega", "stats"):
+        ctx.set_pipeline("staged" if mode == "staged" else "mega")
+        ctx.reset_counters()
+        outs[mode] = ctx.render_region((0, 0, w, h), spp, spp_max=2 * spp, stats=(mode == "stats"))
+        cnts[mode] = ctx.counters()
+        if mode == "staged":
+            if "staged" not in ctx.kernel_name():
+                pytest.skip("scene is not staged-eligible")
+            st = ctx.staged_stats()
+            assert st["jobs_done"] == st["jobs_queued"] > 0
+    for mode in ("staged", "mega"):
+        for a, b in zip(outs[mode], outs["stats"]):
+            assert np.array_equal(bits(a), bits(b)), mode
+        assert all(cnts[mode][k] == cnts["stats"][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), mode
+    assert cnts["stats"]["tri_tests"] > 0
+
+
+def _write_big_fuzz_scene(tmp, rng, kind):
+    """Meshes of a few thousand triangles (beyond LDS, so the 4-wide tree and the staged integrator take them) built to
+    hit the corners of the reference's mesh search: exactly coplanar axis-aligned sheets cut into many triangles (flat
+    leaf boxes, hits on shared edges, ties between coincident sheets), a closed bumpy shell seen from inside and
+    outside, random soup with duplicated triangles, and a second instance of the same mesh touching the first."""
+    v, f = [], []
+
+    def tri(a, b, c):
+        base = len(v)
+        v.extend([a, b, c])
+        f.append((base + 1, base + 2, base + 3))
+
+    def grid(origin, du, dv, n, bump=0.0):
+        P = [[origin + du * (i / n) + dv * (j / n) + bump * np.sin(3.1 * i) * np.cos(2.3 * j) * np.cross(du, dv) / np.linalg.norm(np.cross(du, dv))
+              for j in range(n + 1)] for i in range(n + 1)]
+        for i in range(n):
+            for j in range(n):
+                tri(P[i][j], P[i + 1][j], P[i + 1][j + 1])
+                tri(P[i][j], P[i + 1][j + 1], P[i][j + 1])
+
+    X, Y, Z = np.eye(3)
+    if kind == "sheets":      # coplanar axis-aligned sheets, two of them coincident, one offset by one ulp-ish amount
+        for z in (-2.0, 0.0, 0.0, 0.0 + 1e-6, 3.0):
+            grid(np.array([-5.0, -5.0, z]), 10 * X, 10 * Y, 12)
+        grid(np.array([2.0, -5.0, -4.0]), 10 * Y, 9 * Z, 12)     # a wall the sheets run into
+    elif kind == "shell":     # closed box with bumpy faces around the origin: rays start inside after the first bounce
+        for s in (-1.0, 1.0):
+            grid(np.array([-4.0, -4.0, 4.0 * s]), 8 * X, 8 * Y, 14, bump=0.05)
+            grid(np.array([-4.0, 4.0 * s, -4.0]), 8 * X, 8 * Z, 14, bump=0.05)
+            grid(np.array([4.0 * s, -4.0, -4.0]), 8 * Y, 8 * Z, 14, bump=0.05)
+    else:                     # "soup": random triangles, every fourth one repeated exactly, a few degenerate
+        for k in range(700):
+            c = rng.uniform(-5, 5, 3)
+            t = c + rng.uniform(-1.2, 1.2, (3, 3))
+            tri(*t)
+            if k % 4 == 0:
+                tri(*t)
+            if k % 50 == 0:
+                tri(t[0], t[0], t[1])
+    with open(os.path.join(tmp, "fuzz.obj"), "w") as o:
+        for p in v:
+            o.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for t in f:
+            o.write("f %d %d %d\n" % t)
+    glass = kind == "shell"
+    xml = """<xml><scene>
+      <object type="obj" name="fuzz.obj" material="%s"><rotate angle="%s" x="1" y="0.3" z="0.1"/><translate x="0.5" z="1"/></object>
+      <object type="obj" name="fuzz.obj" material="m"><scale value="0.5"/><translate x="0.5" y="3" z="1"/></object>
+      <object type="sphere" name="ball" material="g"><scale value="1.5"/><translate x="-3" y="-6" z="0"/></object>
+      <object type="plane" name="floor" material="m"><scale value="40"/><translate z="-7"/></object>
+      <material type="blinn" name="m"><diffuse r="0.7" g="0.6" b="0.5"/><specular value="0.3"/><glossiness value="20"/><emission value="0.1"/></material>
+      <material type="blinn" name="g"><diffuse value="0.05"/><specular value="0.8"/><glossiness value="60"/><refraction value="0.9" index="1.4"/>
+        <absorption r="0.05" g="0.1" b="0.2"/></material>
+      <light type="point" name="l"><intensity value="60"/><position x="3" y="-9" z="11"/></light>
+      <light type="direct" name="d"><intensity value="0.4"/><direction x="-0.3" y="0.5" z="-1"/></light>
+    </scene><camera><position x="0" y="-24" z="7"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="40"/>
+      <width value="128"/><height value="96"/></camera></xml>""" % ("g" if glass else "m", "0" if kind == "sheets" else "20")
+    path = os.path.join(tmp, "fuzz.xml")
+    open(path, "w").write(xml)
+    return path
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("kind", ["sheets", "shell", "soup"])
+def test_big_fuzz_meshes_all_searches_agree(ctx, tmp_path, kind, seed):
+    """Non-resident fuzz meshes: staged == megakernel (4-wide tree) == counting kernel (reference walk) bit for bit, and
+    depth / cast counts == the CPU oracle.  The sheets case makes the searches disagree about WHICH of two coincident
+    triangles is hit unless ties and the order check send those rays to the exact walk - the test fails if they do not."""
+    from oracle import binding as oracle
+    from qaray_amd.host import load_scene_blob
+    rng = np.random.default_rng(100 * seed + {"sheets": 1, "shell": 2, "soup": 3}[kind])
+    xml = _write_big_fuzz_scene(str(tmp_path), rng, kind)
+    w, h, spp = 160 + 32 * seed, 120, 4
+    blob = load_scene_blob(xml, size=(w, h), asset_root=str(tmp_path))
+    ctx.upload_scene(blob)
+    outs, cnts = {}, {}
+    for mode in ("staged", "mega", "stats"):
+        ctx.set_pipeline("staged" if mode == "staged" else "mega")
+        ctx.reset_counters()
+        outs[mode] = ctx.render_region((0, 0, w, h), spp, stats=(mode == "stats"))
+        cnts[mode] = ctx.counters()
+        if mode == "staged":
+            assert "staged" in ctx.kernel_name(), "fuzz scene should be staged-eligible: " + ctx.kernel_name()
+    for mode in ("staged", "mega"):
+        for a, b in zip(outs[mode], outs["stats"]):
+            assert np.array_equal(bits(a), bits(b)), mode
+        assert (cnts[mode]["casts_normal"], cnts[mode]["casts_shadow"]) == (cnts["stats"]["casts_normal"], cnts["stats"]["casts_shadow"]), mode
+    o = oracle.render(blob, (0, 0, w, h), spp)
+    assert np.array_equal(bits(o[1]), bits(outs["stats"][1]))
+    assert (cnts["stats"]["casts_normal"], cnts["stats"]["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
+    assert rmse(np.nan_to_num(outs["stats"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
+
+
+def test_exact_repeat_is_exercised_and_invisible(ctx, tmp_path):
+    """Coincident sheets: the staged integrator must send rays to wf_redo (ties / failed order checks) - and the frame
+    must not show it."""
+    from qaray_amd.host import load_scene_blob
+    xml = _write_big_fuzz_scene(str(tmp_path), np.random.default_rng(7), "sheets")
+    blob = load_scene_blob(xml, size=(256, 192), asset_root=str(tmp_path))
+    ctx.upload_scene(blob)
+    ctx.set_pipeline("staged")
+    ctx.reset_counters()
+    a = ctx.render_region((0, 0, 256, 192), 4)
+    st = ctx.staged_stats()
+    assert st["rays_redone"] > 0, st
+    ctx.set_pipeline("mega")
+    b = ctx.render_region((0, 0, 256, 192), 4, stats=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(bits(x), bits(y))
+
+
+def test_staged_strips_partition_and_determinism(ctx):
+    """Round-robin 8-row strips (the multi-GPU partition) through the staged integrator == the whole frame, twice."""
+    import torch
+    from qaray_amd import distributed as qd, hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    W, H, spp = 480, 270, 4
+    ctx.upload_scene(load_scene_blob("trc_scene_tower.xml", size=(W, H)))
+    ctx.set_pipeline("staged")
+    full = ctx.render_region((0, 0, W, H), spp)
+    again = ctx.render_region((0, 0, W, H), spp)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(full, again))
+    crop = ctx.render_region((101, 33, 322, 201), spp)[0]
+    assert np.array_equal(bits(crop), bits(full[0][33:201, 101:322]))
+    dev = torch.device("cuda", 0)
+    world = 3
+    asm = np.zeros((H, W, 3), np.float32)
+    for r in range(world):
+        n = hip.strip_count(0, H, r, world) * 8
+        rgb = torch.zeros((n, W, 3), dtype=torch.float32, device=dev)
+        d = torch.zeros((n, W), dtype=torch.float32, device=dev)
+        ns = torch.zeros((n, W), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.render_strips_device((0, 0, W, H), r, world, spp, rgb, d, ns)
+        ctx.synchronize()
+        qd.place_strips(asm, rgb.cpu().numpy(), H, world, r)
+    assert np.array_equal(bits(asm), bits(full[0]))
+
+
+def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
+    """QA_PIPE_AUTO: the first large frame is preceded by a timed 4-spp probe of both integrators; whatever it picks, the
+    frame equals the megakernel's, and the probe leaves the counters alone."""
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    W, H, spp = 1280, 720, 64
+    ctx.upload_scene(load_scene_blob("trc_scene_tower.xml", size=(W, H)))
+    ctx.set_pipeline("auto")
+    assert "probe" in ctx.kernel_name() and "decided" in ctx.kernel_name()
+    ctx.reset_counters()
+    a = ctx.render_region((0, 0, W, H), spp)
+    ca = ctx.counters()
+    assert "probe: megakernel" in ctx.kernel_name()
+    assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
+    ctx.set_pipeline("mega")
+    ctx.reset_counters()
+    b = ctx.render_region((0, 0, W, H), spp)
+    cb = ctx.counters()
+    for x, y in zip(a, b):
+        assert np.array_equal(bits(x), bits(y))
+    assert ca == cb
+
+
+def test_stop_request_ends_a_staged_frame(ctx):
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    ctx.upload_scene(load_scene_blob("trc_scene_tower.xml", size=(160, 90)))
+    ctx.set_pipeline("staged")
+    ctx.request_stop()
+    rgb, depth, ns = ctx.render_region((0, 0, 160, 90), 4)
+    assert (ns == 0).all()
+    ctx.clear_stop()
+    rgb, depth, ns = ctx.render_region((0, 0, 160, 90), 4)
+    assert (ns == 4).all()
