@@ -10,6 +10,12 @@ at 16:9 with N x 2.07 Mpixel (N=4 is exactly 3840x2160), 8-row strips dealt roun
 scene blob broadcast from rank 0 over RCCL, float radiance strips gathered to rank 0 inside the step.
 Inputs (scene tables) are resident in HBM before the timed region.
 
+--config c2|c3|c4|c5 selects a BASELINE.json config by name (scene, frame, spp).  c2 is the default workload
+(same as no flag).  c3 - c5 keep BASELINE's FIXED frame whatever --gpus is (strong scaling: the 8-row strips of
+the same 1080p / 4K frame are dealt round-robin to the ranks, as the reference's Renderer_MPI does); their meshes
+and textures are the synthetic stand-ins of scenes/gen_assets.py.  --spp overrides the config's spp (a full
+C5 frame is 17 Gsamples).
+
 One JSON line on rank 0; see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
 """
 import argparse
@@ -30,8 +36,20 @@ BYTES_PER_SAMPLE = 24  # radiance accumulate read + write
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def frame_size(n_gpus, base_w, base_h):
-    if n_gpus == 1:
+CONFIGS = {   # BASELINE.json configs[1..4]
+    "c2": dict(scene="example_project12_box.xml", width=1920, height=1080, spp=512, strong=False,
+               what="Cornell box, tinyobjloader cornell_box.obj, 36 triangles"),
+    "c3": dict(scene="example_project7_object.xml", width=1920, height=1080, spp=256, strong=True,
+               what="triangle meshes + textures, synthetic stand-in assets, 114 k triangles in 6 mesh instances"),
+    "c4": dict(scene="example_project12_caustics_glossy.xml", width=3840, height=2160, spp=1024, strong=True,
+               what="glossy caustics box, synthetic stand-in teapots, 56 k triangles in 2 mesh instances"),
+    "c5": dict(scene="trc_scene_tower.xml", width=3840, height=2160, spp=2048, strong=True,
+               what="glass teapot / tower / church, synthetic stand-in assets, 361 k triangles"),
+}
+
+
+def frame_size(n_gpus, base_w, base_h, strong=False):
+    if n_gpus == 1 or strong:
         return base_w, base_h
     s = math.sqrt(n_gpus)
     return int(round(base_w * s)), int(round(base_h * s))
@@ -80,10 +98,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="example_project12_box.xml")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="a BASELINE.json config by name (default: c2's workload, weak scaling)")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--pipeline", choices=["auto", "mega", "staged"], default="auto",
+                    help="integrator for scenes beyond LDS (same bits either way; auto = timed probe, see include/qaray_hip.h)")
     ap.add_argument("--bounce", type=int, default=5)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x51A7A7)
     ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample (0 = skip)")
@@ -97,6 +118,14 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="rank 0: also render the whole frame alone and require the gathered image to equal it bit for bit")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config or "c2"]
+    strong = bool(args.config) and cfg["strong"]
+    args.scene = args.scene or cfg["scene"]
+    args.width = args.width or cfg["width"]
+    args.height = args.height or cfg["height"]
+    args.spp = args.spp or cfg["spp"]
+    if args.scene != "example_project12_box.xml":
+        subprocess.run([sys.executable, os.path.join(ROOT, "scenes", "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
 
     import torch
     import torch.distributed as dist
@@ -121,10 +150,11 @@ def main():
             dist.init_process_group(backend="gloo")
     coll_device = device if args.backend == "nccl" else torch.device("cpu")
 
-    W, H = frame_size(world, args.width, args.height)
+    W, H = frame_size(world, args.width, args.height, strong)
     scene_xml = args.scene if os.path.isabs(args.scene) else os.path.join(SCENES_DIR, args.scene)
 
     ctx = hip.Context(local_rank)
+    ctx.set_pipeline(args.pipeline)
     # rank 0 parses + flattens; everyone receives the blob over RCCL and adopts it from HBM
     blob = load_scene_blob(scene_xml, size=(W, H)) if rank == 0 else None
     if world > 1:
@@ -192,6 +222,8 @@ def main():
 
     kernel_ms, launches = ctx.kernel_time()
     cnt = ctx.counters()
+    kernel_name = ctx.kernel_name()
+    staged = ctx.staged_stats() if kernel_name.startswith("staged") else None
     local = torch.tensor([cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
@@ -207,27 +239,37 @@ def main():
         k_bytes = k_casts * BYTES_PER_CAST + k_samples * BYTES_PER_SAMPLE
         k_ms = kernel_ms / max(launches, 1)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        headline = os.path.basename(scene_xml) == "example_project12_box.xml"
+        what = next((c["what"] for c in CONFIGS.values() if c["scene"] == os.path.basename(scene_xml)), "probe scene, not a BASELINE config")
         out = {
-            "metric": "Msamples/s (1 sample = 1 camera path), Cornell box 1080p@512spp",
+            "metric": "Msamples/s (1 sample = 1 camera path), " + ("Cornell box 1080p@512spp" if headline else f"{os.path.basename(scene_xml)} {W}x{H}@{args.spp}spp"),
             "value": msamples, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"inputs/{os.path.basename(scene_xml)} "
-                                   + ("(Cornell box, tinyobjloader cornell_box.obj, 36 triangles)"
-                                      if os.path.basename(scene_xml) == "example_project12_box.xml" else "(probe scene, not the headline workload)")
+            "config": {"workload": f"inputs/{os.path.basename(scene_xml)} ({what})"
                                    + (f", photon maps {args.photon_map}" if args.photon_map else "")
                                    + f", {W}x{H}, {args.spp} spp, maxBounce {args.bounce}, seed {args.seed:#x}",
+                       "baseline_config": args.config or ("c2" if headline and (args.spp, args.width, args.height) == (512, 1920, 1080) else None),
                        "frame": [W, H], "spp": args.spp, "partition": f"8-row strips round-robin over {world} GPU(s)",
                        "wall_clock_s_per_frame": ms_per_step * 1e-3,
                        "casts_per_sample": (casts_n + casts_s) / max(samples, 1)},
+            # achieved = ALGORITHMIC queue bytes (casts x 144 B + samples x 24 B) per launch / the launch's
+            # duration (HIP events on the launch stream).  That is the contract's figure; it is NOT memory traffic: the
+            # megakernel keeps path state in registers, and both integrators are bound by VALU issue / memory latency.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "qa::qa_integrate<RES=1,LIGHTS=0,TEX=0,AREA=0,STATS=0>", "kernel_ms_avg": k_ms, "launches": int(launches),
+                         "kernel": kernel_name, "kernel_ms_avg": k_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": k_bytes,
-                         "note": "algorithmic bytes = casts x 144 B + samples x 24 B (SURVEY.md 8d); path state "
-                                 "actually lives in VGPRs/LDS, so measured HBM traffic is far below this"},
+                         "actual_limiter": "VALU issue + memory latency (see profiles/ SQ passes), not HBM bandwidth",
+                         "note": "achieved = (casts x 144 B + samples x 24 B) / launch time, SURVEY.md 8d; measured HBM bytes are in "
+                                 "'traffic' when a PMC pass of this kernel and frame is committed under profiles/"},
         }
-        # measured HBM traffic of the same launch shape, from the committed rocprofv3 --pmc passes
+        if staged:
+            # geometry the trace stage read, from its own counters: 128-byte nodes of the 4-wide tree, 48-byte triangle records
+            out["roofline"]["geometry_bytes_per_launch"] = staged["geometry_bytes"] / max(launches, 1)
+            out["roofline"]["trace_lane_utilisation"] = staged["lane_utilisation"]
+            out["roofline"]["staged"] = {k: staged[k] for k in ("passes", "jobs_done", "node_steps", "tri_tests", "rays_redone", "jobs_suspended")}
+        # measured HBM traffic of the same kernel on the same frame, from the committed rocprofv3 --pmc passes
         try:
             prof_dir = os.path.join(ROOT, "profiles")
             best = None
@@ -235,11 +277,14 @@ def main():
                 for f in sorted(os.listdir(os.path.join(prof_dir, d))):
                     if f.endswith("_summary.json"):
                         sj = json.load(open(os.path.join(prof_dir, d, f)))
-                        if sj.get("frame") == [W, H] and sj.get("spp") == args.spp and "hbm_traffic_bytes_per_launch" in sj:
+                        if (sj.get("frame") == [W, H] and sj.get("spp") == args.spp and "hbm_traffic_bytes_per_launch" in sj
+                                and sj.get("kernel_name") == kernel_name and sj.get("scene") == os.path.basename(scene_xml)):
                             best = (sj, os.path.join("profiles", d, f))
             if best:
                 out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes)"
+                out["roofline"]["measured_hbm_gbs"] = best[0]["hbm_traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+                out["roofline"]["traffic_source"] = (best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes; measured on build "
+                                                     + str(best[0].get("build", "?")) + ")")
         except Exception:
             pass
         if world == 1 and args.cpu_spp > 0:
