@@ -60,15 +60,25 @@ const uint8_t *qa_fb_pixels(const qa_fb *fb);        /* RGB8 */
 const float *qa_fb_zbuffer(const qa_fb *fb);
 const uint8_t *qa_fb_sample_count(const qa_fb *fb);
 const uint8_t *qa_fb_mask(const qa_fb *fb);
+/* FrameBuffer::ComputeZBufferImage / ComputeSampleCountImage (src/fb/framebuffer.cpp:62-107), then the 8-bit image */
+const uint8_t *qa_fb_z_image(qa_fb *fb);
+const uint8_t *qa_fb_sample_count_image(qa_fb *fb);
 int qa_fb_num_rendered_pixels(const qa_fb *fb);
 int qa_fb_save_image(const qa_fb *fb, const char *png_path);
 int qa_fb_save_z_image(qa_fb *fb, const char *png_path);
 int qa_fb_save_sample_count_image(qa_fb *fb, const char *png_path);
 
-/* ---- tasking ---- */
+/* ---- tasking (src/tasking/parallel_for.h:59-68); C++ callers use qaray_hip::tasking of csrc/host/framebuffer.h,
+ * which keeps the reference's names and signatures including parallel_for(start, end, step, std::function) and
+ * ThreadLocalStorage<T> ---- */
+void qa_tasking_init(void);
+uint64_t qa_tasking_get_num_of_threads(void);
+void qa_tasking_set_num_of_threads(uint64_t n);
 void qa_tasking_signal_start(void);
 void qa_tasking_signal_stop(void);
 int qa_tasking_has_stop_signal(void);
+/* parallel_for with a C callback: fn(i, user) for i = start, start + step, ... < end on the tasking threads */
+int qa_tasking_parallel_for(uint64_t start, uint64_t end, uint64_t step, void (*fn)(uint64_t, void *), void *user);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@
 static uint32_t g_seed = QA_DEFAULT_SEED;
 static thread_local uint32_t tl_pixel = 0;
 static thread_local uint32_t tl_stream = 0;   // 0: pixel streams; QA_STREAM_PHOTON / QA_STREAM_CAUSTICS: emissions
+namespace qaray { float LinearToSRGB(const float c); }   // src/renderers/renderer.cpp:34
 extern "C" int rand(void) { return (int) qa_pixel_rand(g_seed ^ tl_stream, tl_pixel); }
 extern "C" void srand(unsigned) {}
 
@@ -89,6 +90,7 @@ bool QA_CAT(__wrap_, QA_SYM_SHADOW)(qaray::Scene *s, qaray::Node &n, qaray::Ray 
 struct Options {
   const char *sceneFile = nullptr;
   std::string out = "ref_out";
+  bool eightBit = false, useSRGB = true;   // --eight-bit <srgb 0|1>: also dump the reference's 8-bit products
   int width = -1, height = -1;
   int crop[4] = {0, 0, -1, -1};
   int sppMin = 1, sppMax = 1;
@@ -326,7 +328,7 @@ static void Usage()
 {
   fprintf(stderr,
           "usage: ref_harness scene.xml [--size W H] [--crop x0 y0 x1 y1] [--spp N | --spp-min A --spp-max B]\n"
-          "                   [--bounce B] [--seed S] [--threads T] [--out prefix] [--dump-scene file.json] [--no-render]\n"
+          "                   [--bounce B] [--seed S] [--threads T] [--out prefix] [--dump-scene file.json] [--no-render] [--eight-bit srgb]\n"
           "                   [--photon-map N_PHOTON N_CAUSTICS] [--photon-bounce B B] [--photon-radius R R]\n"
           "       (run with the scene's asset root as the working directory)\n");
 }
@@ -346,6 +348,7 @@ int main(int argc, char **argv)
     else if (s == "--seed") { need(1); g_seed = (uint32_t) strtoul(argv[++a], nullptr, 0); }
     else if (s == "--threads") { need(1); o.threads = atoi(argv[++a]); }
     else if (s == "--out") { need(1); o.out = argv[++a]; }
+    else if (s == "--eight-bit") { need(1); o.eightBit = true; o.useSRGB = atoi(argv[++a]) != 0; }
     else if (s == "--photon-map") { need(2); o.photonMap = true; o.pm.photon.size = (uint32_t) atoi(argv[++a]); o.pm.caustics.size = (uint32_t) atoi(argv[++a]); }
     else if (s == "--photon-bounce") { need(2); o.pm.photon.bounce = (uint32_t) atoi(argv[++a]); o.pm.caustics.bounce = (uint32_t) atoi(argv[++a]); }
     else if (s == "--photon-radius") { need(2); o.pm.photon.radius = (float) atof(argv[++a]); o.pm.caustics.radius = (float) atof(argv[++a]); }
@@ -419,6 +422,35 @@ int main(int argc, char **argv)
     if (!f) { perror(name.c_str()); exit(2); }
     fwrite(p, 1, bytes, f); fclose(f);
   };
+  if (o.eightBit) {
+    // The reference's own 8-bit products of this frame: the tail of Renderer::PixelRender (src/renderers/renderer.cpp:
+    // 347-365) with the reference's LinearToSRGB and MAX / MIN macros, written into the reference's FrameBuffer, whose
+    // ComputeZBufferImage / ComputeSampleCountImage (src/fb/framebuffer.cpp:62-107) then run unchanged.
+    ::FrameBuffer fb;
+    fb.Init((qaUINT) cw, (qaUINT) ch);
+    for (int q = 0; q < cw * ch; ++q) {
+      Color3f color(rgb[3 * (size_t) q], rgb[3 * (size_t) q + 1], rgb[3 * (size_t) q + 2]);
+      if (o.useSRGB) {
+        color.r = qaray::LinearToSRGB(color.r);
+        color.g = qaray::LinearToSRGB(color.g);
+        color.b = qaray::LinearToSRGB(color.b);
+      }
+      color.r = MAX(0.f, MIN(1.f, color.r));
+      color.g = MAX(0.f, MIN(1.f, color.g));
+      color.b = MAX(0.f, MIN(1.f, color.b));
+      fb.GetPixels()[q].r = static_cast<qaUCHAR>(roundf(color.r * 255.f));
+      fb.GetPixels()[q].g = static_cast<qaUCHAR>(roundf(color.g * 255.f));
+      fb.GetPixels()[q].b = static_cast<qaUCHAR>(roundf(color.b * 255.f));
+      fb.GetZBuffer()[q] = depth[q];
+      fb.GetSampleCount()[q] = static_cast<qaUCHAR>(255.f * ns[q] / static_cast<qaFLOAT>(o.sppMax));
+    }
+    fb.ComputeZBufferImage();
+    fb.ComputeSampleCountImage();
+    dump(o.out + ".color.u8", fb.GetPixels(), (size_t) cw * ch * 3);
+    dump(o.out + ".zimg.u8", fb.GetZBufferImage(), (size_t) cw * ch);
+    dump(o.out + ".count.u8", fb.GetSampleCount(), (size_t) cw * ch);
+    dump(o.out + ".countimg.u8", fb.GetSampleCountImage(), (size_t) cw * ch);
+  }
   dump(o.out + ".rgb.f32", rgb.data(), rgb.size() * 4);
   dump(o.out + ".depth.f32", depth.data(), depth.size() * 4);
   dump(o.out + ".ns.u32", ns.data(), ns.size() * 4);

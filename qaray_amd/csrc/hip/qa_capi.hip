@@ -133,7 +133,13 @@ static int PrepareScene(qa_ctx *c)
   const qa_texmap *texmaps = QA_BLOB_PTR(qa_texmap, blob, h->off_texmaps);
   const qa_texture *textures = QA_BLOB_PTR(qa_texture, blob, h->off_textures);
   for (uint32_t i = 0; i < h->num_texmaps; ++i)
-    if (texmaps[i].texture >= (int) h->num_textures) return Fail(QA_EINVAL, "bad texture index");
+    if (texmaps[i].texture < -1 || texmaps[i].texture >= (int) h->num_textures) return Fail(QA_EINVAL, "bad texture index");
+  if (h->background.texmap < -1 || h->background.texmap >= (int) h->num_texmaps || h->environment.texmap < -1 ||
+      h->environment.texmap >= (int) h->num_texmaps)
+    return Fail(QA_EINVAL, "bad background / environment texmap index");
+  // the tables are read in place (4- and 8-byte fields): offsets must be 8-byte aligned
+  for (uint64_t off : {h->off_instances, h->off_meshes, h->off_mtlsets, h->off_materials, h->off_lights, h->off_texmaps, h->off_textures})
+    if (off % 8) return Fail(QA_EINVAL, "table offset is not 8-byte aligned");
   for (uint32_t i = 0; i < h->num_textures; ++i)
     if (textures[i].type == QA_TEX_FILE &&
         (textures[i].width < 0 || textures[i].height < 0 ||
@@ -164,6 +170,8 @@ static int PrepareScene(qa_ctx *c)
         !inside(m.off_vertices, (uint64_t) m.num_vertices * 12) || !inside(m.off_normals, (uint64_t) m.num_normals * 12) ||
         !inside(m.off_texcoords, (uint64_t) m.num_texcoords * 8))
       return Fail(QA_EINVAL, "mesh array outside the blob");
+    if (m.off_bvh_nodes % 4 || m.off_elements % 4 || m.off_faces % 4 || m.off_vertices % 4 || m.off_normals % 4 || m.off_texcoords % 4)
+      return Fail(QA_EINVAL, "mesh array offset is not 4-byte aligned");
     const qa_bvh_node *nodes = QA_BLOB_PTR(qa_bvh_node, blob, m.off_bvh_nodes);
     const uint32_t *elements = QA_BLOB_PTR(uint32_t, blob, m.off_elements);
     const qa_face *faces = QA_BLOB_PTR(qa_face, blob, m.off_faces);
@@ -578,6 +586,8 @@ static int PrepareScene(qa_ctx *c)
   return SelectKernel(c);
 }
 
+static int DrainEvents(qa_ctx *c);
+
 static int OwnTileRows(int y0, int y1, int tile_row0, int tile_row_step)
 {
   const int tilesY = (y1 - y0 + 7) / 8;
@@ -644,7 +654,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
       HIP_TRY(hipStreamSynchronize(s));
       c->orderKey = key;
     }
-    if (!getenv("QA_NO_TILE_ORDER")) rp.tile_order = c->dOrder;
+    if (c->tileOrder) rp.tile_order = c->dOrder;
   }
   rp.stop_flag = c->dStopAlias;
   rp.counters = c->dCounters;
@@ -731,6 +741,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   HIP_TRY(hipEventRecord(ev.b, s));
   c->pending.push_back(ev);
   c->launches++;
+  // a caller that never asks for timers or counters must not grow the event list without bound
+  if (c->pending.size() > 256) return DrainEvents(c);
   return QA_OK;
 }
 
@@ -844,6 +856,7 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   }
   *c->hStop = 0;
   if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
+  c->tileOrder = getenv("QA_NO_TILE_ORDER") == nullptr;
   if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
   if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
   if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
@@ -959,7 +972,7 @@ int qa_render_region(qa_ctx *c, int x0, int y0, int x1, int y1, int spp_min, int
   HIP_TRY(hipMemcpyAsync(depth, c->dDepth, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(ns, c->dNs, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return QA_OK;
+  return DrainEvents(c);   // the frame is complete: fold its event pair into the kernel time
 }
 
 int qa_synchronize(qa_ctx *c)

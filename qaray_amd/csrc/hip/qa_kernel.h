@@ -19,8 +19,8 @@
 //  * The reference's recursion (Shade -> TraceNodeNormal -> Shade ...) is a chain, because exactly
 //    one of reflect / transmit / diffuse is followed per hit; it is unrolled into an iteration
 //    that carries a throughput.  Random numbers are drawn in the reference's order (select, lobe
-//    sample, then the deeper hits); lights that draw random numbers (area lights) are rejected at
-//    upload time because they would need a post-order replay.
+//    sample, then the deeper hits); lights that draw random numbers (area lights) are evaluated by a
+//    post-order replay of the path's hit log when the path ends (AREA kernel variants).
 //  * BVH traversal is "while-while": a lane descends inner nodes until it holds a leaf, then the
 //    wave intersects leaves together; the per-lane visiting order is exactly the reference's
 //    (near child first, far child pushed), which decides ties between equal hit distances.
@@ -834,7 +834,7 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
 
 // ---------------------------------------------------------------------------------------------
 // Lights (src/lights/lights.h:35-171, src/lights/lights.cpp:23-144); area lights (size > 0.01)
-// are rejected at upload.
+// shoot 16 - 64 shadow rays per evaluation and run in the AREA kernel variants.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float inverseSquareFalloff(f3 v) { return qmin(1.f, 1.f / dot(v, v)); }
 
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
 
       if (!found) {
         // background for camera rays (renderer.cpp:337-341), environment otherwise
-        // (MtlBlinn_PhotonMap.cpp:249-251); textured versions are rejected at upload
+        // (MtlBlinn_PhotonMap.cpp:249-251); textured versions: TEX kernel variants
         f3 c = path.primary ? ld3(sc.background) : ld3(sc.environment);
         if (TEX) {
           if (path.primary)

@@ -1,6 +1,12 @@
 // framebuffer.cpp — see framebuffer.h.
 #include "framebuffer.h"
 
+#include <algorithm>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #include <cmath>
 
 #include "image.h"
@@ -87,10 +93,15 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
                           const uint32_t *nsamples, int sppMax, bool useSRGB)
 {
   const int cw = x1 - x0;
+  int deposited = 0;
   for (int j = y0; j < y1; ++j)
     for (int i = x0; i < x1; ++i) {
       const size_t q = (size_t) (j - y0) * cw + (i - x0);
       const size_t idx = (size_t) j * width + i;
+      // nsamples = 0: the pixel was skipped (tasking::signal_stop); the reference leaves such pixels untouched,
+      // mask 0 (src/renderers/renderer.cpp:365,402)
+      if (nsamples[q] == 0) continue;
+      ++deposited;
       float c[3] = {rgb[3 * q], rgb[3 * q + 1], rgb[3 * q + 2]};
       for (int k = 0; k < 3; ++k) {
         if (useSRGB) c[k] = LinearToSRGB(c[k]);
@@ -102,14 +113,60 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
       sampleCount[idx] = static_cast<uint8_t>(255.f * nsamples[q] / static_cast<float>(sppMax));
       mask[idx] = 1;
     }
-  IncrementNumRenderPixel((x1 - x0) * (y1 - y0));
+  IncrementNumRenderPixel(deposited);
 }
 
 namespace tasking {
 static std::atomic<bool> threadStop{false};
+static std::atomic<size_t> numThreads{0};   // 0 = not initialised
 void signal_start() { threadStop = false; }
 void signal_stop() { threadStop = true; }
 bool has_stop_signal() { return threadStop; }
+size_t get_num_of_threads()
+{
+  if (numThreads == 0) init();
+  return numThreads;
+}
+void set_num_of_threads(size_t n) { numThreads = n ? n : 1; }
+void init()
+{
+  if (numThreads == 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    numThreads = hw ? hw : 1;
+  }
+}
+void parallel_for(size_t start, size_t end, size_t step, std::function<void(size_t)> T)
+{
+  if (step == 0 || start >= end) return;
+  const size_t items = (end - start + step - 1) / step;
+  const size_t workers = std::min(get_num_of_threads(), items);
+  if (workers <= 1) {
+    for (size_t i = start; i < end; i += step) T(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr failure;
+  std::mutex failureLock;
+  auto body = [&]() {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= items) return;
+      try { T(start + k * step); }
+      catch (...) {
+        std::lock_guard<std::mutex> g(failureLock);
+        if (!failure) failure = std::current_exception();
+        next = items;   // no further items are handed out
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve(workers - 1);
+  for (size_t w = 1; w < workers; ++w) pool.emplace_back(body);
+  body();
+  for (std::thread &t : pool) t.join();
+  if (failure) std::rethrow_exception(failure);
+}
 }  // namespace tasking
 
 }  // namespace qaray_hip

@@ -5,6 +5,10 @@
 // and PNG dumps.  The GPU path delivers LINEAR FLOAT radiance per region; Deposit() applies the
 // post-process the reference does at the end of PixelRender (src/renderers/renderer.cpp:347-365).
 #pragma once
+#include <cstddef>
+#include <functional>
+#include <map>
+#include <memory>
 #include <atomic>
 #include <cstdint>
 #include <vector>
@@ -51,10 +55,35 @@ class FrameBuffer {
 
 extern FrameBuffer renderImage;  // src/scene/scene.cpp:78
 
-namespace tasking {  // src/tasking/parallel_for.h:59-68: the stop flag every work item polls
+// src/tasking/parallel_for.h:59-95, same names and signatures.  The pixel work itself runs on the GPU (one
+// qa_render_* call replaces ThreadRender's two nested parallel_for loops); what stays on the host - one worker per
+// GPU of a node, strip assembly, file output - can still be spread with parallel_for, and every work item polls
+// the same stop flag (the HIP layer sees it through qa_request_stop).
+namespace tasking {
+size_t get_num_of_threads();
+void set_num_of_threads(size_t num_of_threads);
+void init();                       // thread count <- hardware concurrency unless set_num_of_threads was called
 void signal_start();
 void signal_stop();
 bool has_stop_signal();
+// calls T(i) for i = start, start + step, ... < end on get_num_of_threads() host threads (work items are handed out
+// one at a time, like TBB's simple_partitioner in the reference); returns when all of them have returned
+void parallel_for(size_t start, size_t end, size_t step, std::function<void(size_t)> T);
+
+// one instance of T per worker thread, created from a prototype on first use (the reference keeps one sampler per
+// thread this way, src/core/sampler.h); local() is valid on the calling thread and inside parallel_for bodies
+template <typename T>
+struct ThreadLocalStorage {
+  const T data;
+  explicit ThreadLocalStorage(const T &t) : data(t) {}
+  T &local()
+  {
+    thread_local std::map<const void *, std::unique_ptr<T>> mine;
+    std::unique_ptr<T> &p = mine[this];
+    if (!p) p.reset(new T(data));
+    return *p;
+  }
+};
 }  // namespace tasking
 
 }  // namespace qaray_hip

@@ -118,6 +118,29 @@ int qa_fb_save_sample_count_image(qa_fb *fb, const char *p)
   return fb->fb.SaveSampleCountImage(p) ? QA_OK : Fail(QA_EIO, "cannot write image");
 }
 
+const uint8_t *qa_fb_z_image(qa_fb *fb)
+{
+  if (!fb) return nullptr;
+  fb->fb.ComputeZBufferImage();
+  return fb->fb.GetZBufferImage();
+}
+const uint8_t *qa_fb_sample_count_image(qa_fb *fb)
+{
+  if (!fb) return nullptr;
+  fb->fb.ComputeSampleCountImage();
+  return fb->fb.GetSampleCountImage();
+}
+
+void qa_tasking_init(void) { tasking::init(); }
+uint64_t qa_tasking_get_num_of_threads(void) { return (uint64_t) tasking::get_num_of_threads(); }
+void qa_tasking_set_num_of_threads(uint64_t n) { tasking::set_num_of_threads((size_t) n); }
+int qa_tasking_parallel_for(uint64_t start, uint64_t end, uint64_t step, void (*fn)(uint64_t, void *), void *user)
+{
+  if (!fn || step == 0) return QA_EINVAL;
+  try { tasking::parallel_for((size_t) start, (size_t) end, (size_t) step, [&](size_t i) { fn((uint64_t) i, user); }); }
+  catch (...) { return QA_EINVAL; }
+  return QA_OK;
+}
 void qa_tasking_signal_start(void) { tasking::signal_start(); }
 void qa_tasking_signal_stop(void) { tasking::signal_stop(); }
 int qa_tasking_has_stop_signal(void) { return tasking::has_stop_signal() ? 1 : 0; }

@@ -122,6 +122,7 @@ class Context:
         assert dev_tensor.is_cuda and dev_tensor.is_contiguous()
         _check(lib().qa_scene_upload_device(self._h, dev_tensor.data_ptr(), dev_tensor.numel()))
         self._remember_size(dev_tensor[:256].cpu().numpy())
+        self._photon_sizes = None   # a new scene drops the photon maps
 
     def _remember_size(self, blob_head):
         # qa_flat_header: width/height follow magic,version(8) total_bytes(8) 6 vec3 (72) dof (4)
@@ -180,7 +181,7 @@ class Context:
         assert depth.is_cuda and depth.is_contiguous() and depth.numel() == n and depth.element_size() == 4
         assert ns.is_cuda and ns.is_contiguous() and ns.numel() == n and ns.element_size() == 4
         spp_max = spp if spp_max is None else spp_max
-        sptr = C.c_void_p(stream) if stream else None
+        sptr = self._stream_arg(stream, rgb)
         _check(lib().qa_render_region_device(self._h, x0, y0, x1, y1, spp, spp_max, max_bounce, seed,
                                              QA_RENDER_STATS if stats else 0, rgb.data_ptr(), depth.data_ptr(),
                                              ns.data_ptr(), sptr))
@@ -195,10 +196,21 @@ class Context:
         assert depth.is_cuda and depth.is_contiguous() and depth.numel() == n and depth.element_size() == 4
         assert ns.is_cuda and ns.is_contiguous() and ns.numel() == n and ns.element_size() == 4
         spp_max = spp if spp_max is None else spp_max
-        sptr = C.c_void_p(stream) if stream else None
+        sptr = self._stream_arg(stream, rgb)
         _check(lib().qa_render_strips_device(self._h, x0, y0, x1, y1, first_strip, strip_step, spp, spp_max,
                                              max_bounce, seed, QA_RENDER_STATS if stats else 0, rgb.data_ptr(),
                                              depth.data_ptr(), ns.data_ptr(), sptr))
+
+    @staticmethod
+    def _stream_arg(stream, tensor):
+        """No stream given: the render runs on the context's own non-blocking stream, which is not ordered against
+        torch's streams - so first wait for whatever torch has queued on the tensor's device (e.g. the zero-fill of
+        freshly created output tensors).  The caller still has to synchronize() before reading the outputs."""
+        if stream:
+            return C.c_void_p(stream)
+        import torch
+        torch.cuda.current_stream(tensor.device).synchronize()
+        return None
 
     def synchronize(self):
         _check(lib().qa_synchronize(self._h))

@@ -36,12 +36,18 @@ def lib():
         L.qa_fb_deposit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int]
         for name, rt in (("qa_fb_pixels", C.POINTER(C.c_uint8)), ("qa_fb_zbuffer", C.POINTER(C.c_float)),
-                         ("qa_fb_sample_count", C.POINTER(C.c_uint8)), ("qa_fb_mask", C.POINTER(C.c_uint8))):
+                         ("qa_fb_sample_count", C.POINTER(C.c_uint8)), ("qa_fb_mask", C.POINTER(C.c_uint8)),
+                         ("qa_fb_z_image", C.POINTER(C.c_uint8)), ("qa_fb_sample_count_image", C.POINTER(C.c_uint8))):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = rt
         L.qa_fb_num_rendered_pixels.argtypes = [C.c_void_p]
         for name in ("qa_fb_save_image", "qa_fb_save_z_image", "qa_fb_save_sample_count_image"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_char_p]
+        L.qa_tasking_init.restype = None
+        L.qa_tasking_get_num_of_threads.restype = C.c_uint64
+        L.qa_tasking_set_num_of_threads.argtypes = [C.c_uint64]
+        L.qa_tasking_set_num_of_threads.restype = None
+        L.qa_tasking_parallel_for.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.qa_tasking_signal_start.restype = None
         L.qa_tasking_signal_stop.restype = None
         _lib = L
@@ -140,6 +146,16 @@ class FrameBuffer:
     @property
     def sample_count(self):
         return self._arr(lib().qa_fb_sample_count, (self.height, self.width), np.uint8)
+
+    @property
+    def z_image(self):
+        """FrameBuffer::ComputeZBufferImage's 8-bit visualisation (src/fb/framebuffer.cpp:62-84)."""
+        return self._arr(lib().qa_fb_z_image, (self.height, self.width), np.uint8)
+
+    @property
+    def sample_count_image(self):
+        """FrameBuffer::ComputeSampleCountImage (src/fb/framebuffer.cpp:86-107)."""
+        return self._arr(lib().qa_fb_sample_count_image, (self.height, self.width), np.uint8)
 
     @property
     def mask(self):

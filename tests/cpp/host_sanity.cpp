@@ -35,6 +35,27 @@ int main(int argc, char **argv)
     CHECK(h->magic == QA_FLAT_MAGIC && h->total_bytes == blob.size());
     CHECK(h->num_instances >= 1);
   }
+  // tasking (src/tasking/parallel_for.h:59-95): every index exactly once, strides, thread-local storage, stop flag
+  {
+    tasking::set_num_of_threads(4);
+    CHECK(tasking::get_num_of_threads() == 4);
+    std::vector<int> seen(1000, 0);
+    tasking::parallel_for(3, 1000, 7, [&](size_t i) { seen[i]++; });
+    int bad = 0;
+    for (size_t i = 0; i < seen.size(); ++i) bad += seen[i] != ((i >= 3 && (i - 3) % 7 == 0) ? 1 : 0);
+    CHECK(bad == 0);
+    tasking::ThreadLocalStorage<std::vector<int>> tls(std::vector<int>(1, 0));
+    tasking::parallel_for(0, 64, 1, [&](size_t) { tls.local()[0]++; });
+    CHECK(tls.local()[0] >= 0 && tls.data[0] == 0);
+    tasking::parallel_for(5, 5, 1, [&](size_t) { ++fails; });      // empty range
+    bool thrown = false;
+    try { tasking::parallel_for(0, 100, 1, [&](size_t i) { if (i == 13) throw 13; }); } catch (int v) { thrown = v == 13; }
+    CHECK(thrown);
+    tasking::signal_stop();
+    CHECK(tasking::has_stop_signal());
+    tasking::signal_start();
+    CHECK(!tasking::has_stop_signal());
+  }
   // malformed XML never crashes
   const char *bad[] = {"", "<", "<xml", "<xml><scene></xml>", "<xml a=></xml>", "<xml a='1></xml>", "<!-- x", "<xml><a/><b></c></xml>",
                        "<xml><scene><object type=\"obj\" name=\"nope.obj\"><scale x=\"abc\"/></object></scene><camera/></xml>"};

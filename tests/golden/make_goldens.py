@@ -47,6 +47,15 @@ CASES = [
 ]
 SEED = 0x51A7A7
 
+# the reference's 8-bit products of whole frames (tests/golden/eightbit/): the tail of PixelRender with the reference's
+# LinearToSRGB, and its FrameBuffer's z-buffer / sample-count visualisations (src/renderers/renderer.cpp:347-365,
+# src/fb/framebuffer.cpp:62-107): name, scene, (W,H), spp_min, spp_max, use sRGB
+EIGHTBIT_CASES = [
+    ("fb_box_96x64_4spp_srgb", "example_project12_box.xml", (96, 64), 4, 4, 1),
+    ("fb_sphere_adaptive_64x48_linear", "example_project3_sphere.xml", (64, 48), 4, 32, 0),
+    ("fb_project4_background_48x36_srgb", "example_project4.xml", (48, 36), 2, 2, 1),
+]
+
 # -use-photon-map cases (tests/golden/photon/): name, scene, (W,H), spp, (size, bounce, radius) of the photon map
 # and of the caustics map.  One RNG stream per emission, include/qa_photon.h.
 PHOTON_CASES = [
@@ -85,6 +94,23 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=rgb, depth=depth, ns=ns,
                             meta=np.frombuffer(json.dumps(info).encode(), dtype=np.uint8))
         print(f"{name}: {cw}x{ch} samples={meta['samples']} casts={meta['casts_normal']}+{meta['casts_shadow']}")
+    os.makedirs(os.path.join(HERE, "eightbit"), exist_ok=True)
+    for name, scene, (w, h), smin, smax, srgb in EIGHTBIT_CASES:
+        if only and name not in only:
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "g")
+            cmd = [HARNESS, scene, "--size", str(w), str(h), "--spp-min", str(smin), "--spp-max", str(smax), "--seed", str(SEED),
+                   "--threads", "8", "--out", out, "--eight-bit", str(srgb)]
+            subprocess.run(cmd, cwd=SCENES, check=True, stdout=subprocess.DEVNULL)
+            arrays = dict(color=np.fromfile(out + ".color.u8", np.uint8).reshape(h, w, 3), zimg=np.fromfile(out + ".zimg.u8", np.uint8).reshape(h, w),
+                          count=np.fromfile(out + ".count.u8", np.uint8).reshape(h, w), countimg=np.fromfile(out + ".countimg.u8", np.uint8).reshape(h, w),
+                          rgb=np.fromfile(out + ".rgb.f32", np.float32).reshape(h, w, 3), depth=np.fromfile(out + ".depth.f32", np.float32).reshape(h, w),
+                          ns=np.fromfile(out + ".ns.u32", np.uint32).reshape(h, w))
+        info = dict(scene=scene, width=w, height=h, spp_min=smin, spp_max=smax, bounce=5, seed=SEED, srgb=srgb,
+                    producer="oracle/_ref/ref_harness --eight-bit (the reference's LinearToSRGB and FrameBuffer code)")
+        np.savez_compressed(os.path.join(HERE, "eightbit", name + ".npz"), meta=np.frombuffer(json.dumps(info).encode(), dtype=np.uint8), **arrays)
+        print(f"{name}: color {arrays['color'].mean():.2f} zimg {arrays['zimg'].mean():.2f} countimg {arrays['countimg'].mean():.2f}")
     os.makedirs(os.path.join(HERE, "photon"), exist_ok=True)
     for name, scene, (w, h), spp, pm, cm in PHOTON_CASES:
         if only and name not in only:

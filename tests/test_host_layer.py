@@ -219,3 +219,77 @@ def test_framebuffer_postprocess_matches_reference_formula():
     assert np.array_equal(fb.zbuffer, depth)
     assert np.array_equal(fb.sample_count, (255.0 * ns / 16.0).astype(np.uint8))
     assert fb.mask.all() and fb.num_rendered_pixels == 8
+
+
+def test_tasking_entry_points_keep_the_reference_signatures():
+    """src/tasking/parallel_for.h:59-68 through the C ABI: thread count, parallel_for (every index once), stop flag."""
+    import ctypes as C
+    from qaray_amd import host
+    L = host.lib()
+    L.qa_tasking_init()
+    L.qa_tasking_set_num_of_threads(3)
+    assert L.qa_tasking_get_num_of_threads() == 3
+    hits = (C.c_int * 500)()
+    CB = C.CFUNCTYPE(None, C.c_uint64, C.c_void_p)
+
+    def body(i, user):
+        hits[i] += 1
+    cb = CB(body)
+    assert L.qa_tasking_parallel_for(10, 500, 5, C.cast(cb, C.c_void_p), None) == 0
+    assert [hits[i] for i in range(500)] == [1 if (i >= 10 and (i - 10) % 5 == 0) else 0 for i in range(500)]
+    assert L.qa_tasking_parallel_for(0, 10, 0, C.cast(cb, C.c_void_p), None) != 0   # step 0 is refused
+    L.qa_tasking_signal_stop()
+    assert L.qa_tasking_has_stop_signal() == 1
+    L.qa_tasking_signal_start()
+    assert L.qa_tasking_has_stop_signal() == 0
+
+
+def test_integration_snippet_compiles_against_the_reference_headers(tmp_path):
+    """INTEGRATION.md section 1 shows the binding a maintainer of the reference adds (class Renderer_HIP).  Here the
+    very text of that code block is compiled with the reference's own headers (only where /root/reference exists:
+    the dev container) and the tasking declarations of the host layer are checked against the reference's."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("the reference tree is only present in the dev container")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```cpp\n(// src/renderers/Renderer_HIP\.cpp.*?)```", text, re.S).group(1)
+    src = tmp_path / "Renderer_HIP.cpp"
+    src.write_text("#include <memory>\n#include <stdexcept>\n#include <vector>\n#include <cmath>\n" + block)
+    inc = [f"-I{ref}/src", f"-I{ref}", f"-I{ref}/external", f"-I{ref}/external/glm", f"-I{ROOT}/include"]
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-fpermissive", "-DUSE_GLM", "-DUSE_OMP", "-fopenmp", *inc, str(src)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    # same names and parameter lists as the reference's tasking header
+    ref_h = open(os.path.join(ref, "src", "tasking", "parallel_for.h")).read()
+    ours = open(os.path.join(ROOT, "qaray_amd", "csrc", "host", "framebuffer.h")).read()
+    norm = lambda t: re.sub(r"\s+", " ", t)
+    for decl in ("size_t get_num_of_threads();", "void set_num_of_threads(size_t num_of_threads);", "void init();", "void signal_start();",
+                 "void signal_stop();", "bool has_stop_signal();", "void parallel_for(size_t start, size_t end, size_t step, std::function<void(size_t)> T);"):
+        assert decl in norm(ref_h), decl
+        assert decl in norm(ours), decl
+
+
+def _eightbit_names():
+    d = os.path.join(GOLDEN, "eightbit")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", _eightbit_names())
+def test_framebuffer_products_equal_the_references_own(name):
+    """The host FrameBuffer against 8-bit arrays produced by the REFERENCE's code (oracle/_ref/ref_harness --eight-bit:
+    its LinearToSRGB + clamp + round tail of PixelRender and its FrameBuffer::ComputeZBufferImage /
+    ComputeSampleCountImage): colour bytes, sample-count bytes and both visualisations, byte for byte."""
+    z = np.load(os.path.join(GOLDEN, "eightbit", name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    w, h = meta["width"], meta["height"]
+    fb = FrameBuffer(w, h)
+    fb.deposit(0, 0, w, h, z["rgb"], z["depth"], z["ns"], meta["spp_max"], use_srgb=bool(meta["srgb"]))
+    assert np.array_equal(fb.pixels, z["color"])
+    assert np.array_equal(fb.sample_count, z["count"])
+    assert np.array_equal(fb.z_image, z["zimg"])
+    assert np.array_equal(fb.sample_count_image, z["countimg"])
+    assert fb.num_rendered_pixels == w * h and (fb.mask == 1).all()
+    fb.close()

@@ -16,7 +16,7 @@ def test_host_layer_under_asan_ubsan(tmp_path):
     host = os.path.join(ROOT, "qaray_amd", "csrc", "host")
     srcs = [os.path.join(host, f) for f in ("xml.cpp", "scene.cpp", "mesh.cpp", "image.cpp", "xmlload.cpp", "framebuffer.cpp")]
     exe = str(tmp_path / "host_sanity")
-    cmd = ["g++", "-std=c++17", *SAN, "-ffp-contract=off", f"-I{ROOT}/include", f"-I{host}",
+    cmd = ["g++", "-std=c++17", "-pthread", *SAN, "-ffp-contract=off", f"-I{ROOT}/include", f"-I{host}",
            os.path.join(ROOT, "tests", "cpp", "host_sanity.cpp"), *srcs, "-o", exe]
     subprocess.run(cmd, check=True)
     work = tmp_path / "w"
