@@ -548,7 +548,7 @@ static int PrepareScene(qa_ctx *c)
   // LDS budget per workgroup: resident image + stacks; small scenes stay entirely on the CU
   ds.stackDepth = c->stackDepth;
   // traversal stacks + 6 accumulator floats per lane (mean, variance)
-  const size_t stackBytes = ((size_t) c->stackDepth + 6) * QA_BLOCK * sizeof(uint32_t);
+  const size_t stackBytes = ((size_t) c->stackDepth + QA_LANE_SLOTS) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = image.size() * sizeof(uint4);
   if (stackBytes > kMaxLdsPerBlock) return Fail(QA_EUNSUPPORTED, "BVH too deep for the LDS traversal stack");
   c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget &&

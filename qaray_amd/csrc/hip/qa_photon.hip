@@ -550,7 +550,7 @@ int qa_photon_maps_build(qa_ctx *c, const qa_photon_params *pp, uint32_t seed)
   uint32_t levels = 1;
   for (uint32_t n = std::max(pp->photon.size, pp->caustics.size); n > 1; n >>= 1) ++levels;
   const uint32_t needDepth = std::max(c->stackDepth, 2 * (levels + 2));
-  const size_t stackBytes = ((size_t) needDepth + 6) * QA_BLOCK * sizeof(uint32_t);
+  const size_t stackBytes = ((size_t) needDepth + QA_LANE_SLOTS) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = c->resident ? (size_t) c->ds.residentVec4 * sizeof(uint4) : 0;
   if (imageBytes + stackBytes > 64 * 1024) return Fail(QA_EUNSUPPORTED, "photon map too deep for the LDS stack");
 

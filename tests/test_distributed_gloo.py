@@ -48,7 +48,7 @@ def _worker(rank, world, port, W, H, spp, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H", [(2, 36), (3, 41)])
+@pytest.mark.parametrize("world,H", [(2, 36), (3, 41), (4, 70), (8, 150)])   # 4 and 8: BASELINE C4 / C5 rank counts
 def test_strip_partition_gather_equals_single_process(tmp_path, world, H):
     W, spp = 40, 2
     out = str(tmp_path / "full.npy")

@@ -384,3 +384,25 @@ def test_two_rank_bench_rehearsal_equals_single_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["check"] is True
     assert d["config"]["frame"] == [453, 255]   # 320x180 scaled by sqrt(2): weak scaling in resolution
+
+
+@pytest.mark.parametrize("ranks,config,size", [(4, "c4", (384, 216)), (2, "c5", (480, 270))])
+def test_strong_scaling_rehearsal_of_baseline_multi_gpu_configs(ranks, config, size):
+    """BASELINE C4 / C5 are FIXED frames cut over 4 / 8 GPUs (strong scaling).  Rehearsal of bench.py --config on this
+    one-GPU box: the ranks share the GPU, collectives over gloo; the frame must keep its size and the gathered image
+    must equal the frame rendered by one rank, bit for bit (the staged integrator and the megakernel both render strips)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--check", "--config", config,
+           "--steps", "1", "--warmup", "0", "--spp", "4", "--width", str(size[0]), "--height", str(size[1]), "--cpu-spp", "0", "--pipeline", "staged"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == ranks and d["check"] is True and d["scaling"] == "strong"
+    assert d["config"]["frame"] == list(size) and d["config"]["baseline_config"] == config
