@@ -29,8 +29,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "qa_device_math.h"
 #include "qa_scene_dev.h"
 #include "qa_seed.h"
@@ -64,21 +62,6 @@ struct SceneMem {
 };
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
-
-// Frame counters.  Counting kernels (QA_RENDER_STATS) keep DCounters per lane.  The others count with the wave:
-// an increment is the number of lanes that execute it (one ballot), added to the wave's tally in LDS by one lane -
-// six 64-bit per-lane counters were 12 VGPRs held through the whole kernel.  NullTally: callers that do not count.
-struct WaveCount {
-  unsigned long long *slot;    // LDS
-  __device__ __forceinline__ void operator++(int)
-  {
-    const unsigned long long m = __ballot(true);
-    if ((int) __lane_id() == __ffsll((long long) m) - 1) *slot += (unsigned long long) __popcll(m);
-  }
-};
-struct WaveTally { WaveCount samples, casts_normal, casts_shadow, bvh_nodes, tri_tests, pixels; };
-struct NullCount { __device__ __forceinline__ void operator++(int) {} };
-struct NullTally { NullCount samples, casts_normal, casts_shadow, bvh_nodes, tri_tests, pixels; };
 
 }  // namespace qa
 #include "qa_photon_dev.h"   // needs QA_BLOCK and asF
@@ -461,9 +444,9 @@ struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element ord
 // with non-strict box tests, and `tie` is raised when a triangle passes the inside test at exactly
 // the distance already held.  Returns whether a triangle was accepted; best = its element index in
 // the walked tree's order.  closest = false stops at the first accepted triangle.
-template <bool FAST, bool STATS, class CNT>
+template <bool FAST, bool STATS>
 __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, uint32_t rootData, const Ray &ray, f3 drcp,
-                                        bool fastSlab, float &hz, bool closest, uint32_t *stack, CNT &cnt,
+                                        bool fastSlab, float &hz, bool closest, uint32_t *stack, DCounters &cnt,
                                         uint32_t &best, bool &tie, float pad = 0.f)
 {
   const f3 pLo = ray.p + F3(pad, pad, pad), pHi = ray.p - F3(pad, pad, pad);   // FAST only
@@ -614,24 +597,6 @@ __device__ __forceinline__ bool insideCancelReach(const DMesh &m, f3 o)
   return reach2 * 1.0001f < m.cancelDist * m.cancelDist;
 }
 
-// The rare repeat of a query on the reference's tree (1 - 2 % of the queries): kept out of line so that the hot
-// path's register allocation does not have to hold two walks.
-__device__ __noinline__ bool walkReferenceOutOfLine(const uint4 *nodes, const uint4 *tris, uint32_t rootData, f3 rp, f3 rd, f3 drcp, bool fastSlab,
-                                                    float *hz, bool closest, uint32_t *stack, uint32_t *best)
-{
-  NullTally none;
-  Ray ray;
-  ray.p = rp;
-  ray.d = rd;
-  bool tie = false;
-  float z = *hz;
-  uint32_t b = *best;
-  const bool hit = walkBVH<false, false>(nodes, tris, rootData, ray, drcp, fastSlab, z, closest, stack, none, b, tie);
-  *hz = z;
-  *best = b;
-  return hit;
-}
-
 // Would the reference's walk have reached the leaf `leaf` of its tree?  It enters a node when the
 // strict box test passes against the distance held at that moment.  Every inner box of the tree is
 // the union of its children's boxes (min / max of the same floats), and the slab arithmetic is
@@ -661,9 +626,9 @@ __device__ __forceinline__ bool refReaches(const uint4 *nodes, uint32_t leaf, co
 // tests per cast on the Cornell box) and then check the answer against the reference's rules:
 // the found triangle must be reachable in the reference's tree (refReaches) and no tie may have
 // been seen; otherwise the lane repeats the query on the reference's tree.
-template <bool RES, bool STATS, class CNT>
+template <bool RES, bool STATS>
 __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m, const Ray &ray, Hit &h, int k,
-                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, CNT &cnt,
+                                        bool closest, uint32_t *stack /* LDS, stride QA_BLOCK */, DCounters &cnt,
                                         TriPick &pick, uint32_t stackCap = 0xFFFFu)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
@@ -763,11 +728,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     }
     if (redo) {
       h.z = hz0;
-#ifndef QA_REDO_OUTLINE
       hasHit = walkBVH<false, false>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
-#else
-      hasHit = walkReferenceOutOfLine(nodes, tris, m.rootData, ray.p, ray.d, drcp, fastSlab, &h.z, closest, stack, &bestTri);   // measured 10 % slower
-#endif
     }
   }
   if (!closest) return hasHit;
@@ -796,9 +757,9 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
 // Scene::TraceNodeNormal (src/scene/scene.cpp:50-74): closest hit over every node in pre-order.
 // TEX: also maintains HitInfo::uvw / duvw / hasTexture exactly as the intersectors do (fields are
 // only overwritten by the object types that set them, so stale values survive like in the reference).
-template <bool RES, bool TEX, bool STATS, class CNT>
+template <bool RES, bool TEX, bool STATS>
 __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DScene &sc, const Ray &world, const RayDiff &wd,
-                                             Hit &h, TexHit &th, uint32_t *stack, CNT &cnt)
+                                             Hit &h, TexHit &th, uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_normal++;
   const Ray r0 = rootRay<RES>(sc, world);
@@ -846,9 +807,9 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
 }
 
 // GenLight::Shadow -> Scene::TraceNodeShadow (src/lights/lights.cpp:39-48, src/scene/scene.cpp:35-46)
-template <bool RES, bool STATS, class CNT>
+template <bool RES, bool STATS>
 __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &sc, const Ray &world, float t_max,
-                                        uint32_t *stack, CNT &cnt)
+                                        uint32_t *stack, DCounters &cnt)
 {
   cnt.casts_shadow++;
   Hit h;
@@ -888,9 +849,9 @@ __device__ __forceinline__ float spotAttenuation(const qa_light &l, f3 p)
   return rr < l.inner ? 1.f : qpowf((l.outer - rr) / (l.outer - l.inner), 2.f);
 }
 
-template <bool RES, bool STATS, class CNT>
+template <bool RES, bool STATS>
 __device__ __forceinline__ f3 illuminate(const SceneMem<RES> mem, const DScene &sc, const qa_light &l, f3 p,
-                                         uint32_t *stack, CNT &cnt, uint32_t &rng)
+                                         uint32_t *stack, DCounters &cnt, uint32_t &rng)
 {
   const f3 intensity = ld3(l.intensity);
   if (l.type != QA_LIGHT_DIRECT && l.size > 0.01f) {
@@ -935,9 +896,9 @@ __device__ __forceinline__ f3 lightDirection(const qa_light &l, f3 p)
 
 // Direct lighting of one shading point (MtlBlinn_PhotonMap.cpp:481-498): every non-ambient light,
 // weight 1/#lights (ambient counted), Blinn lobe around the half vector.
-template <bool RES, bool STATS, class CNT>
+template <bool RES, bool STATS>
 __device__ __forceinline__ f3 directLight(const SceneMem<RES> mem, const DScene &sc, f3 p, f3 N, f3 V, f3 kd, f3 ks,
-                                          float gloss, uint32_t *stack, CNT &cnt, uint32_t &rng)
+                                          float gloss, uint32_t *stack, DCounters &cnt, uint32_t &rng)
 {
   f3 sum = F3(0, 0, 0);
   const float normCoefDI = 1.f / (float) sc.num_lights;
@@ -1098,6 +1059,8 @@ __device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const DSc
 // ---------------------------------------------------------------------------------------------
 struct Path {
   Ray ray;          // next ray to trace (world space)
+  f3 T;             // throughput
+  f3 L;             // radiance gathered by this sample so far
   int absorbMtl;    // material the current ray was spawned from: its absorption applies on a
                     // back-face exit (Beer's law, ComputeSecondaryRay :244-248); -1 for camera rays
   int bounce;       // bounceCount the next hit is shaded with
@@ -1124,10 +1087,7 @@ struct Path {
 // every other variant loses more to the extra spills than the added latency hiding returns
 // (resident glass-sphere room -36 %, project7_object -8 %, glossy caustics -10 %); 6 loses everywhere.
 #ifndef QA_C2_EXTRA_WAVE
-#define QA_C2_EXTRA_WAVE 1
-#endif
-#ifndef QA_TL_LDS
-#define QA_TL_LDS 0      /* 1: throughput / radiance of the running sample in the lane's LDS slots instead of registers */
+#define QA_C2_EXTRA_WAVE 1   /* 0: four waves per SIMD for that variant too - spill-free and 6 % slower (profiles/round02/c2_register_variants.txt) */
 #endif
 #define QA_WAVES_FOR(RES, LIGHTS) (((RES) && !(LIGHTS)) ? QA_MIN_WAVES + QA_C2_EXTRA_WAVE : QA_MIN_WAVES)
 
@@ -1157,19 +1117,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
   const unsigned lane = __lane_id();
 
-  __shared__ unsigned long long s_tally[QA_BLOCK / 64][6];
-#ifndef QA_LANE_TALLY
-#define QA_LANE_TALLY 1     /* 0: count with wave-level tallies in LDS (frees 12 VGPRs, measured 4 % slower at five waves per SIMD) */
-#endif
-  constexpr bool laneTally = STATS || QA_LANE_TALLY;
-  typename std::conditional<laneTally, DCounters, WaveTally>::type cnt;
-  if constexpr (laneTally) cnt = DCounters{0, 0, 0, 0, 0, 0};
-  else {
-    unsigned long long *mine = s_tally[threadIdx.x / 64];
-    if (lane < 6) mine[lane] = 0;
-    cnt.samples.slot = mine + 0; cnt.casts_normal.slot = mine + 1; cnt.casts_shadow.slot = mine + 2;
-    cnt.bvh_nodes.slot = mine + 3; cnt.tri_tests.slot = mine + 4; cnt.pixels.slot = mine + 5;
-  }
+  DCounters cnt = {0, 0, 0, 0, 0, 0};
   TexTables tt;
   tt.blob = sc.blob;
   tt.texmap = sc.texmap;
@@ -1182,8 +1130,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   pathDiff.dx = pathDiff.dy = F3(0, 0, 1);
 
   // pixel state
-  uint32_t pxy = 0;         // pixel x | y << 16
-  f3 regT = F3(0, 0, 0), regL = F3(0, 0, 0);   // throughput / radiance of the running sample (QA_TL_LDS = 0)
+  int px = 0, py = 0;
   unsigned q = 0;           // output index of the pixel
   uint32_t rng = 1;
   int sidx = 0;
@@ -1191,6 +1138,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   path.primary = true;
   path.ray.p = F3(0, 0, 0);
   path.ray.d = F3(0, 0, 1);
+  path.T = F3(0, 0, 0);
+  path.L = F3(0, 0, 0);
   path.absorbMtl = -1;
   path.bounce = 0;
   path.fromDiffuse = false;
@@ -1221,12 +1170,12 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           const unsigned tx = (tile % tilesX) * 8 + (in % 8);
           const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
           if (tx < (unsigned) rw && ty < (unsigned) rh) {
-            const int px = rp.x0 + (int) tx, py = rp.y0 + (int) ty;
-            pxy = (uint32_t) px | ((uint32_t) py << 16);
+            px = rp.x0 + (int) tx;
+            py = rp.y0 + (int) ty;
             q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
             rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
             sidx = 0;
-            for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;   // mean, variance (slots 6..11: T, L of the running sample)
+            for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;
             needSample = true;
             needPixel = false;
           }
@@ -1242,7 +1191,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
     const bool goSample = !rp.sync_samples || (__ballot(needSample) == __ballot(alive && !needPixel));
     if (alive && needSample && goSample) {
       const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
-      texpos = F3(hx, hy, 0.f) + F3((float) (pxy & 0xFFFFu), (float) (pxy >> 16), 0.f);
+      texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
       const f3 cpt = (A + U * texpos.x) + V * texpos.y;
       f3 campos = ld3(sc.cam.pos);
@@ -1262,13 +1211,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         pathDiff.dx = normalize(xpt - campos);
         pathDiff.dy = normalize(ypt - campos);
       }
-#if QA_TL_LDS
-      acc[6 * QA_BLOCK] = 1.f; acc[7 * QA_BLOCK] = 1.f; acc[8 * QA_BLOCK] = 1.f;      // T
-      acc[9 * QA_BLOCK] = 0.f; acc[10 * QA_BLOCK] = 0.f; acc[11 * QA_BLOCK] = 0.f;    // L
-#else
-      regT = F3(1, 1, 1);
-      regL = F3(0, 0, 0);
-#endif
+      path.T = F3(1, 1, 1);
+      path.L = F3(0, 0, 0);
       path.absorbMtl = -1;
       path.bounce = rp.max_bounce;
       path.fromDiffuse = false;
@@ -1293,14 +1237,6 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       th.duvw0 = th.duvw1 = F3(0, 0, 0);
       th.hasTexture = false;
       const bool found = traceClosest<RES, TEX, STATS>(mem, sc, path.ray, pathDiff, h, th, stack, cnt);
-      // throughput and radiance of the running sample live in the lane's LDS slots: nothing in the BVH walks needs them,
-      // and held in registers they were what the allocator spilled to scratch once per cast
-#if QA_TL_LDS
-      f3 curT = F3(acc[6 * QA_BLOCK], acc[7 * QA_BLOCK], acc[8 * QA_BLOCK]);
-      f3 curL = F3(acc[9 * QA_BLOCK], acc[10 * QA_BLOCK], acc[11 * QA_BLOCK]);
-#else
-      f3 &curT = regT, &curL = regL;
-#endif
       if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
 
       if (!found) {
@@ -1313,7 +1249,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           else
             c = sampleEnvironment(tt, c, sc.envTexmap, path.ray.d);
         }
-        curL = curL + curT * c;
+        path.L = path.L + path.T * c;
         done = true;
       } else {
         // ---- D. shade: MtlBlinn_PhotonMap::Shade (MtlBlinn_PhotonMap.cpp:256-500) -----------
@@ -1322,7 +1258,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         if (!path.primary && !h.front && path.absorbMtl >= 0) {
           const uint4 ab = mtlTable[6 * (size_t) path.absorbMtl + 5];
           const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
-          curT = curT * att;
+          path.T = path.T * att;
         }
         const qa_instance &in = instAt<RES>(sc, h.node);
         int mi = -1;
@@ -1335,14 +1271,14 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           } else mi = ms.first;
         }
         if (mi < 0) {
-          if (white) curL = curL + curT;
+          if (white) path.L = path.L + path.T;
           done = true;
         } else {
           const f3 V = -path.ray.d;
           const f3 N = h.N;
           const f3 p = h.p;
           const Surface sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, path.bounce, path.fromDiffuse, rng);
-          curL = curL + curT * sf.emission;
+          path.L = path.L + path.T * sf.emission;
           const f3 sampleDiffuse = sf.kd, sampleSpecular = sf.ks;
           const float glossSpec = sf.gloss;
           const bool spawn = sf.spawn;
@@ -1354,16 +1290,16 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             // a heap share a cache line that way: 10 - 12 % faster than slot-major columns)
             uint2 *heap = rp.heap + ((size_t) blockIdx.x * QA_BLOCK + threadIdx.x) * (QA_PHOTON_GATHER + 1);
             if (path.fromDiffuse)
-              curL = curL + curT * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
-            curL = curL + curT * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
+              path.L = path.L + path.T * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
+            path.L = path.L + path.T * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
           }
 
           // direct lighting (:481-498)
           if (LIGHTS && !AREA) {
-            curL = curL + curT * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng);
+            path.L = path.L + path.T * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng);
           }
           if (AREA && nrec < QA_MAX_PATH) {
-            const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, curT.x, curT.y, curT.z,
+            const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, path.T.x, path.T.y, path.T.z,
                                             sampleDiffuse.x, sampleDiffuse.y, sampleDiffuse.z,
                                             sampleSpecular.x, sampleSpecular.y, sampleSpecular.z, glossSpec};
             for (int f = 0; f < QA_REC_FLOATS; ++f) rec[(size_t) (nrec * QA_REC_FLOATS + f) * recStride] = v[f];
@@ -1375,7 +1311,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             path.ray.p = p;
             path.ray.d = normalize(nextDir);
             if (TEX) pathDiff.dx = pathDiff.dy = path.ray.d;  // DiffRay(pos, dir): x = y = c (ray.h:57-63)
-            curT = curT * bxdf;
+            path.T = path.T * bxdf;
             path.absorbMtl = mi;
             path.bounce -= 1;
             path.fromDiffuse = nextFromDiffuse;
@@ -1385,33 +1321,24 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           }
         }
       }
-#if QA_TL_LDS
-      acc[6 * QA_BLOCK] = curT.x; acc[7 * QA_BLOCK] = curT.y; acc[8 * QA_BLOCK] = curT.z;
-      acc[9 * QA_BLOCK] = curL.x; acc[10 * QA_BLOCK] = curL.y; acc[11 * QA_BLOCK] = curL.z;
-#endif
     }
 
     // ---- E. sample finished: SuperSamplerHalton::Accumulate / Loop (scene.cpp:92-121) ---------
     if (alive && done) {
-#if QA_TL_LDS
-      f3 curL = F3(acc[9 * QA_BLOCK], acc[10 * QA_BLOCK], acc[11 * QA_BLOCK]);
-#else
-      f3 &curL = regL;
-#endif
       if (AREA) {
         for (int lvl = nrec - 1; lvl >= 0; --lvl) {
           float v[QA_REC_FLOATS];
           for (int f = 0; f < QA_REC_FLOATS; ++f) v[f] = rec[(size_t) (lvl * QA_REC_FLOATS + f) * recStride];
           const f3 d = directLight<RES, STATS>(mem, sc, F3(v[0], v[1], v[2]), F3(v[3], v[4], v[5]), F3(v[6], v[7], v[8]),
                                                F3(v[12], v[13], v[14]), F3(v[15], v[16], v[17]), v[18], stack, cnt, rng);
-          curL = curL + F3(v[9], v[10], v[11]) * d;
+          path.L = path.L + F3(v[9], v[10], v[11]) * d;
         }
         nrec = 0;
       }
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
       f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
-      const f3 dc = (curL - mean) / inv;
+      const f3 dc = (path.L - mean) / inv;
       mean = mean + dc;
       if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
       acc[0] = mean.x; acc[QA_BLOCK] = mean.y; acc[2 * QA_BLOCK] = mean.z;
@@ -1432,18 +1359,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
     }
   }
 
-  // ---- counters: one atomic per wave and counter
+  // ---- counters: wave reduction, one atomic per wave and counter -----------------------------
+  unsigned long long v[6] = {cnt.samples, cnt.casts_normal, cnt.casts_shadow, cnt.bvh_nodes, cnt.tri_tests, cnt.pixels};
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(rp.counters);
-  if constexpr (laneTally) {
-    unsigned long long v[6] = {cnt.samples, cnt.casts_normal, cnt.casts_shadow, cnt.bvh_nodes, cnt.tri_tests, cnt.pixels};
-    for (int i = 0; i < 6; ++i) {
-      unsigned long long x = v[i];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-      if (lane == 0 && x) atomicAdd(&dst[i], x);
-    }
-  } else {
-    const unsigned long long x = lane < 6 ? s_tally[threadIdx.x / 64][lane < 6 ? lane : 0] : 0ull;
-    if (lane < 6 && x) atomicAdd(&dst[lane], x);
+  for (int i = 0; i < 6; ++i) {
+    unsigned long long x = v[i];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if (lane == 0 && x) atomicAdd(&dst[i], x);
   }
 }
 

@@ -108,7 +108,7 @@ struct DMesh {
   float cancelDist;            // ray origins farther out than this keep the reference tree
 };
 
-#define QA_LANE_SLOTS 12  /* per-lane LDS floats behind the traversal stack: mean, variance, throughput, radiance */
+#define QA_LANE_SLOTS 6   /* per-lane LDS floats behind the traversal stack: running mean and variance of the pixel */
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
 #define QA_KARG_MESH 4
 

@@ -68,3 +68,4 @@ def test_powf_expf_strided_sweep(tmp_path):
         r = subprocess.run([exe, hip.HIP_LIB_PATH, mode, "16"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         assert " 0 mismatches" in r.stdout
+

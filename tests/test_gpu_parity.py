@@ -406,3 +406,4 @@ def test_strong_scaling_rehearsal_of_baseline_multi_gpu_configs(ranks, config, s
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == ranks and d["check"] is True and d["scaling"] == "strong"
     assert d["config"]["frame"] == list(size) and d["config"]["baseline_config"] == config
+
