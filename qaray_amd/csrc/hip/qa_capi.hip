@@ -417,6 +417,7 @@ static int PrepareScene(qa_ctx *c)
     dm.stackNeed = stackNeed;
     dm.wrootWord = allWide[mi].rootWord;
     dm.wideStack = 3 * allWide[mi].depth + 2;
+    dm.wnodeCount = (uint32_t) allWide[mi].nodes.size();
     dm.nearPad = meshSlack[mi].nearPad;
     dm.cancelDist = meshSlack[mi].cancelDist;
     {
@@ -858,6 +859,8 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
   c->tileOrder = getenv("QA_NO_TILE_ORDER") == nullptr;
   if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
+  if (const char *e = getenv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
+  if (const char *e = getenv("QA_WF_TOP_KB")) c->wf.topKB = (uint32_t) std::max(0, atoi(e));
   if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
   if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {

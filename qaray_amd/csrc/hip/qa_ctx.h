@@ -34,15 +34,28 @@ struct WfHost {
   float probeMs[2] = {0.f, 0.f};
   int numLights = 0;            // non-ambient lights
   int32_t lightIdx[QA_WF_MAX_LIGHTS] = {0, 0, 0, 0};
-  WfBuf buf{};
-  size_t capSlots = 0;
-  int capLights = -1;
-  std::vector<void *> allocs;
-  WfCounters *dCtr = nullptr, *hCtr = nullptr;   // one per iteration of a chunk (device / pinned host)
+  // The frame's 8x8 tiles are dealt round-robin to a few GROUPS; each group has its own slot state, queues and counters
+  // and drives its own logic -> cull -> trace -> redo chain on its own stream, so that the (latency-bound, tail-heavy)
+  // kernels of different groups overlap on the chip.
+  struct Group {
+    WfBuf buf{};
+    size_t capSlots = 0;
+    int capLights = -1;
+    std::vector<void *> allocs;
+    WfCounters *dCtr = nullptr, *hCtr = nullptr;   // one per iteration of a chunk (device / pinned host)
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool finished = false;
+  };
+  static const int kMaxGroups = 8;
+  Group groups[kMaxGroups];
+  int numGroups = 3;            // QA_WF_GROUPS
+  hipEvent_t start = nullptr;
   WfStats *dStats = nullptr;
   // diagnostics of the frames rendered since the last reset
   uint64_t iterations = 0, raysClosest = 0, raysShadow = 0, jobs = 0, redo = 0;
-  int traceBlocksPerCU = 0;     // 0 = ask the occupancy API at the first frame
+  int traceBlocksPerCU = 0;     // QA_WF_BLOCKS: workgroups per CU of every stage kernel of one group (0 = 2 with several groups, what fits with one)
+  uint32_t topKB = 0;           // KB of LDS for the top levels of the wide trees in wf_trace (QA_WF_TOP_KB); measured slower, off
   uint32_t stackCap = 24;       // LDS stack entries per lane of wf_trace (QA_WF_STACK)
   uint32_t budget = 512;        // BVH steps a job may take per pass (QA_WF_BUDGET)
 };

@@ -512,6 +512,46 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
   return hasHit;
 }
 
+// The four children of a DWideNode (qa_scene_dev.h, its 4 x 16 bytes in q0..q3) against a ray whose origin has been
+// split into pLo / pHi (origin -/+ pad: the boxes widened by `pad`): K = entry distance of child c, or +inf when the
+// ray misses it, the slot is empty or the box lies beyond hz; W = its child word.  Boxes are decoded with one fma per
+// plane - conservative by construction (quantised outwards, checked by the builder with the same fma).
+#define QA_WIDE_BYTE(X, C) ((float) (((X) >> (8 * (C))) & 0xFFu))
+#define QA_WIDE_CHILD(K, W, C)                                                                                                       \
+  {                                                                                                                                  \
+    const f3 lo = F3(__builtin_fmaf(QA_WIDE_BYTE(q1.z, C), asF(q0.w), asF(q0.x)), __builtin_fmaf(QA_WIDE_BYTE(q1.w, C), asF(q1.x), asF(q0.y)), \
+                     __builtin_fmaf(QA_WIDE_BYTE(q2.x, C), asF(q1.y), asF(q0.z)));                                                   \
+    const f3 hi = F3(__builtin_fmaf(QA_WIDE_BYTE(q2.y, C), asF(q0.w), asF(q0.x)), __builtin_fmaf(QA_WIDE_BYTE(q2.z, C), asF(q1.x), asF(q0.y)), \
+                     __builtin_fmaf(QA_WIDE_BYTE(q2.w, C), asF(q1.y), asF(q0.z)));                                                   \
+    const f3 p0 = (lo - pLo) * drcp, p1 = (hi - pHi) * drcp;                                                                         \
+    const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z)); \
+    const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z)); \
+    K = (W != QA_DONE && en <= hz && en <= ex) ? en : INF;                                                                           \
+  }
+#define QA_WIDE_CE(KA, WA, KB, WB)  \
+  {                                 \
+    const bool sw = KA > KB;        \
+    const float tk = sw ? KB : KA;  \
+    KB = sw ? KA : KB;              \
+    KA = tk;                        \
+    const uint32_t tw = sw ? WB : WA; \
+    WB = sw ? WA : WB;              \
+    WA = tw;                        \
+  }
+// all four children, sorted by entry distance (missed ones last, K = +inf)
+#define QA_WIDE_NODE(q0, q1, q2, q3)                          \
+  float k0, k1, k2, k3;                                       \
+  uint32_t w0 = q3.x, w1 = q3.y, w2 = q3.z, w3 = q3.w;        \
+  QA_WIDE_CHILD(k0, w0, 0)                                    \
+  QA_WIDE_CHILD(k1, w1, 1)                                    \
+  QA_WIDE_CHILD(k2, w2, 2)                                    \
+  QA_WIDE_CHILD(k3, w3, 3)                                    \
+  QA_WIDE_CE(k0, w0, k1, w1)                                  \
+  QA_WIDE_CE(k2, w2, k3, w3)                                  \
+  QA_WIDE_CE(k0, w0, k2, w2)                                  \
+  QA_WIDE_CE(k1, w1, k3, w3)                                  \
+  QA_WIDE_CE(k1, w1, k2, w2)
+
 // One walk of the library's 4-wide tree over the reference tree's leaves (qa_widebvh.h).  Boxes are widened by
 // `pad` (folded into two copies of the origin) and tested non-strictly, so every reference leaf the ray can have
 // an accepted hit in is visited; children are entered nearest first.  Leaves are the reference's own (same
@@ -528,38 +568,9 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
   uint32_t cur = rootWord;
   while (cur != QA_DONE) {
     while (!(cur & QA_BVH_LEAF_BIT)) {
-      const uint4 *nd = wn + 8 * (size_t) cur;
-      const uint4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hzz = nd[5], ch = nd[6];
-      float k0, k1, k2, k3;
-      uint32_t w0 = ch.x, w1 = ch.y, w2 = ch.z, w3 = ch.w;
-#define QA_WIDE_CHILD(K, W, LX, LY, LZ, HX, HY, HZ)                                                                           \
-      {                                                                                                                        \
-        const f3 p0 = (F3(asF(LX), asF(LY), asF(LZ)) - pLo) * drcp, p1 = (F3(asF(HX), asF(HY), asF(HZ)) - pHi) * drcp;        \
-        const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z)); \
-        const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z)); \
-        K = (W != QA_DONE && en <= hz && en <= ex) ? en : INF;                                                                 \
-      }
-      QA_WIDE_CHILD(k0, w0, lx.x, ly.x, lz.x, hx.x, hy.x, hzz.x)
-      QA_WIDE_CHILD(k1, w1, lx.y, ly.y, lz.y, hx.y, hy.y, hzz.y)
-      QA_WIDE_CHILD(k2, w2, lx.z, ly.z, lz.z, hx.z, hy.z, hzz.z)
-      QA_WIDE_CHILD(k3, w3, lx.w, ly.w, lz.w, hx.w, hy.w, hzz.w)
-#undef QA_WIDE_CHILD
-#define QA_WIDE_CE(KA, WA, KB, WB)                                  \
-      {                                                             \
-        const bool sw = KA > KB;                                    \
-        const float tk = sw ? KB : KA;                              \
-        KB = sw ? KA : KB;                                          \
-        KA = tk;                                                    \
-        const uint32_t tw = sw ? WB : WA;                           \
-        WB = sw ? WA : WB;                                          \
-        WA = tw;                                                    \
-      }
-      QA_WIDE_CE(k0, w0, k1, w1)
-      QA_WIDE_CE(k2, w2, k3, w3)
-      QA_WIDE_CE(k0, w0, k2, w2)
-      QA_WIDE_CE(k1, w1, k3, w3)
-      QA_WIDE_CE(k1, w1, k2, w2)
-#undef QA_WIDE_CE
+      const uint4 *nd = wn + 4 * (size_t) cur;
+      const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      QA_WIDE_NODE(q0, q1, q2, q3)
       // nearest child next, the others stacked farthest first
       if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
       if (k2 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w2; else tie = true; }

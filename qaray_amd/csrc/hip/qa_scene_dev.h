@@ -64,16 +64,22 @@ static_assert(sizeof(DMaterial) == 96, "DMaterial must be 6 x 16 bytes");
 #define QA_MTL_SPECULAR_LOBES 1u
 #define QA_MTL_HAS_SPECULAR 2u
 
-// Node of the library's own 4-wide search tree for global-memory meshes (qa_widebvh.h): four child boxes in SoA
-// form, four child words (inner: node index; leaf: the reference leaf's own word = flag + triangle range;
-// QA_DONE: empty slot) and the reference-tree ids of leaf children.  8 x 16 bytes.
-struct alignas(128) DWideNode {
-  float lo[3][4];
-  float hi[3][4];
+// Node of the library's own 4-wide search tree for global-memory meshes (qa_widebvh.h), 64 bytes = 4 x 16:
+//   q0 = origin.xyz, scale.x         q1 = scale.y, scale.z, lo.x[4 children as bytes], lo.y[4]
+//   q2 = lo.z[4], hi.x[4], hi.y[4], hi.z[4]      q3 = child words
+// Child c's box on axis a is [origin.a + lo.a[c] * scale.a, origin.a + hi.a[c] * scale.a] (one fma each), quantised
+// OUTWARDS on the node's own 8-bit grid (scale = a power of two): the search only needs boxes that CONTAIN the
+// reference's leaf boxes, and the traversal is bound by the number of scattered 16-byte accesses, not by arithmetic.
+// Child words: inner = node index (breadth-first numbering: the first nodes of a tree are its top levels, which the
+// staged trace stage keeps in LDS); leaf = the reference leaf's own word (flag + triangle range); QA_DONE = empty.
+struct alignas(64) DWideNode {
+  float origin[3];
+  float scale[3];
+  uint32_t lo[3];     // byte c = child c
+  uint32_t hi[3];
   uint32_t child[4];
-  uint32_t refLeaf[4];
 };
-static_assert(sizeof(DWideNode) == 128, "DWideNode must be 8 x 16 bytes");
+static_assert(sizeof(DWideNode) == 64, "DWideNode must be 4 x 16 bytes");
 
 struct DMesh {
   float bmin[3], bmax[3];
@@ -103,6 +109,7 @@ struct DMesh {
   const DWideNode *wnodes;
   uint32_t wrootWord;          // child word of the root
   uint32_t useWide;
+  uint32_t wnodeCount;         // nodes of the wide tree
   uint32_t wideStack;          // stack entries a walk of the wide tree can need (3 per level + 2)
   float nearPad;               // fp32 slack of the reference's inside test (qa_widebvh.h ComputeMeshSlack)
   float cancelDist;            // ray origins farther out than this keep the reference tree

@@ -37,16 +37,16 @@ __device__ __forceinline__ uint32_t wfInfo(uint32_t sidx, uint32_t bounce, bool 
 
 // Decode a slot: tile-major (a wave of wf_logic = one 8x8 pixel tile, like the megakernel's work items).
 struct WfPixel { int px, py; unsigned q; bool valid; };
-__device__ __forceinline__ WfPixel wfPixel(const RenderParams &rp, unsigned slot)
+__device__ __forceinline__ WfPixel wfPixel(const RenderParams &rp, const WfBuf &b, unsigned slot)
 {
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
-  const unsigned in = slot % 64, tile = slot / 64;
+  const unsigned in = slot % 64, tile = (slot / 64) * b.groupCount + b.groupIndex;   // the group's tiles are interleaved with the others'
   const unsigned otr = tile / tilesX;
   const unsigned tx = (tile % tilesX) * 8 + (in % 8);
   const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
   WfPixel o;
-  o.valid = tx < (unsigned) rw && ty < (unsigned) rh;
+  o.valid = tx < (unsigned) rw && ty < (unsigned) rh && otr < (unsigned) rp.own_tile_rows;
   o.px = rp.x0 + (int) tx;
   o.py = rp.y0 + (int) ty;
   o.q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
@@ -65,7 +65,7 @@ __global__ void wf_init(const DScene sc, const RenderParams rp, WfBuf b)
 {
   const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= b.n) return;
-  const WfPixel px = wfPixel(rp, slot);
+  const WfPixel px = wfPixel(rp, b, slot);
   uint32_t rng = 1, info = wfInfo(0, 0, false, true, WF_PH_DONE, 0);
   if (px.valid) {
     rng = qa_pixel_seed(rp.seed, (uint32_t) px.py * (uint32_t) sc.cam.width + (uint32_t) px.px);
@@ -274,7 +274,7 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
     Ray ray;
     ray.p = F3(P4.x, P4.y, P4.z);
     ray.d = F3(D4.x, D4.y, D4.z);
-    const WfPixel px = wfPixel(rp, slot);
+    const WfPixel px = wfPixel(rp, b, slot);
     TexTables tt;
     tt.blob = sc.blob;
     tt.texmap = sc.texmap;
@@ -464,8 +464,10 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
   return e;
 }
 
+// waves per SIMD the allocator must leave room for: four without textures (+5 - 8 % on the tower / glossy scenes against
+// two); the textured variant spills 167 registers at that budget and is 2 % faster at two
 template <bool TEX>
-__global__ __launch_bounds__(QA_BLOCK) void wf_logic(const DScene sc, const RenderParams rp, WfBuf b, WfCounters *ctr, DCounters *frame,
+__global__ __launch_bounds__(QA_BLOCK, TEX ? 2 : 4) void wf_logic(const DScene sc, const RenderParams rp, WfBuf b, WfCounters *ctr, DCounters *frame,
                                                      uint32_t parity)
 {
   __shared__ uint32_t s_q[QA_BLOCK / 64][2][QA_WF_RAYQ_CAP];
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
 {
   extern __shared__ uint4 s_dyn[];
   __shared__ unsigned long long s_wnodes[32], s_tris[32], s_nodes[32], s_shade[32];
-  __shared__ uint32_t s_root[32];
+  __shared__ uint32_t s_root[32], s_topOff[32], s_topCnt[32];
   __shared__ float s_pad[32], s_absMax[32];
   if (threadIdx.x < 32) {
     const int k = (int) threadIdx.x;
@@ -747,10 +749,16 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     s_root[k] = root;
     s_pad[k] = pad;
     s_absMax[k] = am;
+    s_topOff[k] = b.instTopOff[k];
+    s_topCnt[k] = b.instTopCnt[k];
   }
-  __syncthreads();
   uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn) + threadIdx.x;   // entry s at stack[s * QA_BLOCK]
   const uint32_t cap = b.traceStack;
+  // the top levels of the trees: LDS behind the stacks
+  uint4 *s_top = s_dyn + (size_t) cap * (QA_BLOCK / 4);
+  for (uint32_t c = 0; c < b.topCopies; ++c)
+    for (uint32_t i = threadIdx.x; i < 4 * b.topCnt[c]; i += QA_BLOCK) s_top[b.topOff[c] + i] = b.topSrc[c][i];
+  __syncthreads();
   const unsigned lane = __lane_id();
   const unsigned nCont = min(b.contCount[parity], b.contCap), nNew = min(ctr->nJobs, b.jobCap);
   const unsigned total = nCont + nNew;
@@ -760,7 +768,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
   f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), drcp = F3(0, 0, 1);
   float hz = 0.f, hz0 = 0.f, pad = 0.f;
   uint32_t bits = 0, best = QA_WF_NOBEST, cur = QA_DONE, sp = 0, steps = 0;
-  const uint4 *wn = nullptr, *tris = nullptr;
+  const uint4 *wn = nullptr, *tris = nullptr, *topNodes = s_top;
+  uint32_t topCnt = 0, nTop = 0;
   uint32_t rNext = 0, rEnd = 0;                       // the wave's reserved range of job indices (wave-uniform)
   uint32_t nNode = 0, nLeaf = 0, nTri = 0, nJobsDone = 0, nSusp = 0, nFlag = 0;
   unsigned long long nSlots = 0, nRounds = 0;
@@ -859,6 +868,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
           const uint32_t k = bits >> 27;
           wn = reinterpret_cast<const uint4 *>(s_wnodes[k]);
           tris = reinterpret_cast<const uint4 *>(s_tris[k]);
+          topNodes = s_top + s_topOff[k];
+          topCnt = s_topCnt[k];
           pad = s_pad[k] + 1e-6f * (qmax(qmax(qabs(lo.x), qabs(lo.y)), qabs(lo.z)) + s_absMax[k]);
           if (my >= nCont) cur = s_root[k];
           steps = 0;
@@ -871,44 +882,44 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     }
 
     // ---- one round: the body more lanes wait for
+#ifndef QA_WF_IFIF
+#define QA_WF_IFIF 0     /* 1: every round runs the node body and then the leaf body (every walking lane advances) */
+#endif
     const bool atInner = have && !over && !(cur & QA_BVH_LEAF_BIT);
+#if QA_WF_IFIF
+    const int nI = __popcll(__ballot(atInner));
+    if (nI > 0) {
+#else
     const bool atLeaf = have && !over && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE;
     const int nI = __popcll(__ballot(atInner)), nL = __popcll(__ballot(atLeaf));
     if (nI >= nL && nI > 0) {
+#endif
       if (atInner) {
         const f3 pLo = lo + F3(pad, pad, pad), pHi = lo - F3(pad, pad, pad);
-        const uint4 *nd = wn + 8 * (size_t) cur;
-        const uint4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hzz = nd[5], ch = nd[6];
+        // the top levels of every tree sit in LDS (breadth-first numbering: node index < topCnt), the rest in global memory
+        uint4 q0, q1, q2, q3;
+        if (cur < topCnt) {
+          const uint4 *nd = topNodes + 4 * (size_t) cur;
+          q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+          ++nTop;
+        } else {
+          const uint4 *nd = wn + 4 * (size_t) cur;
+          q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+        }
+#ifdef QA_WF_NOSORT
         float k0, k1, k2, k3;
-        uint32_t w0 = ch.x, w1 = ch.y, w2 = ch.z, w3 = ch.w;
-#define QA_WIDE_CHILD(K, W, LX, LY, LZ, HX, HY, HZ)                                                                           \
-        {                                                                                                                      \
-          const f3 p0 = (F3(asF(LX), asF(LY), asF(LZ)) - pLo) * drcp, p1 = (F3(asF(HX), asF(HY), asF(HZ)) - pHi) * drcp;      \
-          const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z)); \
-          const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z)); \
-          K = (W != QA_DONE && en <= hz && en <= ex) ? en : INF;                                                               \
-        }
-        QA_WIDE_CHILD(k0, w0, lx.x, ly.x, lz.x, hx.x, hy.x, hzz.x)
-        QA_WIDE_CHILD(k1, w1, lx.y, ly.y, lz.y, hx.y, hy.y, hzz.y)
-        QA_WIDE_CHILD(k2, w2, lx.z, ly.z, lz.z, hx.z, hy.z, hzz.z)
-        QA_WIDE_CHILD(k3, w3, lx.w, ly.w, lz.w, hx.w, hy.w, hzz.w)
-#undef QA_WIDE_CHILD
-#define QA_WIDE_CE(KA, WA, KB, WB)                                  \
-        {                                                           \
-          const bool sw = KA > KB;                                  \
-          const float tk = sw ? KB : KA;                            \
-          KB = sw ? KA : KB;                                        \
-          KA = tk;                                                  \
-          const uint32_t tw = sw ? WB : WA;                         \
-          WB = sw ? WA : WB;                                        \
-          WA = tw;                                                  \
-        }
+        uint32_t w0 = q3.x, w1 = q3.y, w2 = q3.z, w3 = q3.w;
+        QA_WIDE_CHILD(k0, w0, 0)
+        QA_WIDE_CHILD(k1, w1, 1)
+        QA_WIDE_CHILD(k2, w2, 2)
+        QA_WIDE_CHILD(k3, w3, 3)
+        // only the nearest child is picked out (three compare-exchanges instead of five); the rest keep their order
         QA_WIDE_CE(k0, w0, k1, w1)
-        QA_WIDE_CE(k2, w2, k3, w3)
         QA_WIDE_CE(k0, w0, k2, w2)
-        QA_WIDE_CE(k1, w1, k3, w3)
-        QA_WIDE_CE(k1, w1, k2, w2)
-#undef QA_WIDE_CE
+        QA_WIDE_CE(k0, w0, k3, w3)
+#else
+        QA_WIDE_NODE(q0, q1, q2, q3)
+#endif
         if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
         if (k2 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w2; else tie = true; }
         if (k1 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w1; else tie = true; }
@@ -919,7 +930,14 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
       }
       nSlots += (unsigned) nI;
       ++nRounds;
-    } else if (nL > 0) {
+    }
+#if QA_WF_IFIF
+    const bool atLeaf = have && !over && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE;   // includes lanes that have just reached a leaf
+    const int nL = __popcll(__ballot(atLeaf));
+    if (nL > 0) {
+#else
+    else if (nL > 0) {
+#endif
       if (atLeaf) {
         Ray ray;
         ray.p = lo;
@@ -948,6 +966,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
 
   // ---- statistics: one atomic per wave and counter
   unsigned long long v[8] = {nJobsDone, nNode, nLeaf, nTri, nFlag, nSusp, nSlots, nRounds};
+  (void) nTop;
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(b.stats);
   for (int i = 0; i < 8; ++i) {
     unsigned long long x = v[i];

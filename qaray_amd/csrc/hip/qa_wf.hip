@@ -15,47 +15,49 @@
 
 namespace {
 
-const int kChunk = 16;   // iterations between two looks at the "pixels still running" counter
+const int kChunk = 16;   // iterations between two looks at the "pixels still running" counters
 
-void FreeBuffers(WfHost &w)
+typedef WfHost::Group Group;
+
+void FreeBuffers(Group &g)
 {
-  for (void *p : w.allocs) (void) hipFree(p);
-  w.allocs.clear();
-  w.capSlots = 0;
-  w.capLights = -1;
-  memset(&w.buf, 0, sizeof(w.buf));
+  for (void *p : g.allocs) (void) hipFree(p);
+  g.allocs.clear();
+  g.capSlots = 0;
+  g.capLights = -1;
+  memset(&g.buf, 0, sizeof(g.buf));
 }
 
 template <class T>
-int Alloc(WfHost &w, T **out, size_t count)
+int Alloc(Group &g, T **out, size_t count)
 {
   void *p = nullptr;
   HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
-  w.allocs.push_back(p);
+  g.allocs.push_back(p);
   *out = static_cast<T *>(p);
   return QA_OK;
 }
 
-int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth, uint32_t traceStack)
+int EnsureBuffers(qa_ctx *c, Group &g, size_t slots, int lights, uint32_t stackDepth, uint32_t traceStack)
 {
   WfHost &w = c->wf;
-  if (!w.dCtr) {
-    HIP_TRY(hipMalloc((void **) &w.dCtr, kChunk * sizeof(WfCounters)));
-    HIP_TRY(hipMalloc((void **) &w.dStats, sizeof(WfStats)));
-    HIP_TRY(hipMemset(w.dStats, 0, sizeof(WfStats)));
-    HIP_TRY(hipHostMalloc((void **) &w.hCtr, kChunk * sizeof(WfCounters), hipHostMallocDefault));
+  if (!g.dCtr) {
+    HIP_TRY(hipMalloc((void **) &g.dCtr, kChunk * sizeof(WfCounters)));
+    HIP_TRY(hipHostMalloc((void **) &g.hCtr, kChunk * sizeof(WfCounters), hipHostMallocDefault));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
   }
-  if (slots <= w.capSlots && lights == w.capLights && stackDepth == w.buf.stackDepth && traceStack == w.buf.traceStack) return QA_OK;
-  FreeBuffers(w);
-  WfBuf &b = w.buf;
+  if (slots <= g.capSlots && lights == g.capLights && stackDepth == g.buf.stackDepth && traceStack == g.buf.traceStack) return QA_OK;
+  FreeBuffers(g);
+  WfBuf &b = g.buf;
   int rc;
   const size_t nl = (size_t) std::max(lights, 1);
-  if ((rc = Alloc(w, &b.P, slots)) || (rc = Alloc(w, &b.D, slots)) || (rc = Alloc(w, &b.T, slots)) || (rc = Alloc(w, &b.L, slots)) ||
-      (rc = Alloc(w, &b.mean, slots)) || (rc = Alloc(w, &b.cstd, slots)) || (rc = Alloc(w, &b.Tp, slots)) ||
-      (rc = Alloc(w, &b.SH, slots * nl)) || (rc = Alloc(w, &b.C, slots * nl)) || (rc = Alloc(w, &b.key, slots)) ||
-      (rc = Alloc(w, &b.vis, slots)) || (rc = Alloc(w, &b.rayq, slots * (1 + nl))) || (rc = Alloc(w, &b.redoq, slots * (1 + nl))) ||
-      (rc = Alloc(w, &b.out, slots)) || (rc = Alloc(w, &b.redoFlag, slots)) || (rc = Alloc(w, &b.contCount, 2))) {
-    FreeBuffers(w);
+  if ((rc = Alloc(g, &b.P, slots)) || (rc = Alloc(g, &b.D, slots)) || (rc = Alloc(g, &b.T, slots)) || (rc = Alloc(g, &b.L, slots)) ||
+      (rc = Alloc(g, &b.mean, slots)) || (rc = Alloc(g, &b.cstd, slots)) || (rc = Alloc(g, &b.Tp, slots)) ||
+      (rc = Alloc(g, &b.SH, slots * nl)) || (rc = Alloc(g, &b.C, slots * nl)) || (rc = Alloc(g, &b.key, slots)) ||
+      (rc = Alloc(g, &b.vis, slots)) || (rc = Alloc(g, &b.rayq, slots * (1 + nl))) || (rc = Alloc(g, &b.redoq, slots * (1 + nl))) ||
+      (rc = Alloc(g, &b.out, slots)) || (rc = Alloc(g, &b.redoFlag, slots)) || (rc = Alloc(g, &b.contCount, 2))) {
+    FreeBuffers(g);
     return rc;
   }
   // job queue: a ray enters the bounds of ~1 mesh on average; rays the queue cannot take go to the exact repeat
@@ -63,13 +65,13 @@ int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth, uint
   b.contCap = (uint32_t) std::max<size_t>(b.jobCap / 4, 4096);
   b.stackDepth = stackDepth;
   b.traceStack = traceStack;
-  if ((rc = Alloc(w, &b.jobA, b.jobCap)) || (rc = Alloc(w, &b.jobB, b.jobCap))) { FreeBuffers(w); return rc; }
+  if ((rc = Alloc(g, &b.jobA, b.jobCap)) || (rc = Alloc(g, &b.jobB, b.jobCap))) { FreeBuffers(g); return rc; }
   for (int k = 0; k < 2; ++k)
-    if ((rc = Alloc(w, &b.contA[k], b.contCap)) || (rc = Alloc(w, &b.contB[k], b.contCap)) || (rc = Alloc(w, &b.contC[k], b.contCap)) ||
-        (rc = Alloc(w, &b.contStack[k], (size_t) b.contCap * traceStack))) { FreeBuffers(w); return rc; }
+    if ((rc = Alloc(g, &b.contA[k], b.contCap)) || (rc = Alloc(g, &b.contB[k], b.contCap)) || (rc = Alloc(g, &b.contC[k], b.contCap)) ||
+        (rc = Alloc(g, &b.contStack[k], (size_t) b.contCap * traceStack))) { FreeBuffers(g); return rc; }
   b.stats = w.dStats;
-  w.capSlots = slots;
-  w.capLights = lights;
+  g.capSlots = slots;
+  g.capLights = lights;
   return QA_OK;
 }
 
@@ -77,13 +79,19 @@ int EnsureBuffers(qa_ctx *c, size_t slots, int lights, uint32_t stackDepth, uint
 
 void FreeStaged(qa_ctx *c)
 {
-  FreeBuffers(c->wf);
-  if (c->wf.dCtr) (void) hipFree(c->wf.dCtr);
-  if (c->wf.dStats) (void) hipFree(c->wf.dStats);
-  if (c->wf.hCtr) (void) hipHostFree(c->wf.hCtr);
-  c->wf.dCtr = nullptr;
-  c->wf.dStats = nullptr;
-  c->wf.hCtr = nullptr;
+  WfHost &w = c->wf;
+  for (Group &g : w.groups) {
+    FreeBuffers(g);
+    if (g.dCtr) (void) hipFree(g.dCtr);
+    if (g.hCtr) (void) hipHostFree(g.hCtr);
+    if (g.stream) (void) hipStreamDestroy(g.stream);
+    if (g.done) (void) hipEventDestroy(g.done);
+    g.dCtr = nullptr; g.hCtr = nullptr; g.stream = nullptr; g.done = nullptr;
+  }
+  if (w.dStats) (void) hipFree(w.dStats);
+  if (w.start) (void) hipEventDestroy(w.start);
+  w.dStats = nullptr;
+  w.start = nullptr;
 }
 
 // Which scenes the staged integrator takes (decided once per upload).  Everything else keeps the megakernel.
@@ -144,70 +152,165 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
   WfHost &w = c->wf;
   const int rw = rp.x1 - rp.x0;
   const size_t tilesX = (size_t) (rw + 7) / 8;
-  const size_t slots = tilesX * (size_t) rp.own_tile_rows * 64;
+  const size_t tiles = tilesX * (size_t) rp.own_tile_rows;
+  // groups: at least ~2000 tiles each, or the frame is too small to be worth splitting
+  int G = std::max(1, std::min(w.numGroups, WfHost::kMaxGroups));
+  while (G > 1 && tiles / G < 2048) --G;
   // wf_trace's stacks: what the wide trees can need, capped (QA_WF_STACK, default 24): nearest-first walks rarely hold
   // more than a dozen entries, and every LDS kilobyte saved is occupancy; a full stack sends the ray to wf_redo
   uint32_t wideNeed = 2;
   for (const DMesh &dm : c->hostMeshes) if (dm.useWide) wideNeed = std::max(wideNeed, dm.wideStack);
   const uint32_t traceStack = std::min(wideNeed, w.stackCap);
-  int rc = EnsureBuffers(c, slots, w.numLights, ds.stackDepth, traceStack);
-  if (rc != QA_OK) return rc;
-  WfBuf b = w.buf;
-  b.n = (uint32_t) slots;
-  b.numLights = (uint32_t) w.numLights;
-  for (int j = 0; j < QA_WF_MAX_LIGHTS; ++j) b.lightIdx[j] = w.lightIdx[j];
 
-  const unsigned blocks = (unsigned) ((slots + QA_BLOCK - 1) / QA_BLOCK);
-  hipLaunchKernelGGL(wf_init, dim3(blocks), dim3(QA_BLOCK), 0, s, ds, rp, b);
-  HIP_TRY(hipGetLastError());
-  const size_t stackLds = (size_t) ds.stackDepth * QA_BLOCK * sizeof(uint32_t);
-  const size_t traceLds = (size_t) traceStack * QA_BLOCK * sizeof(uint32_t);
-  if (!w.traceBlocksPerCU) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) wf_trace, QA_BLOCK, traceLds) != hipSuccess || n < 1) n = 2;
-    w.traceBlocksPerCU = std::min(n, 8);
+  // top levels of the wide trees in LDS: QA_WF_TOP_KB KB shared evenly by the distinct meshes (at most 8); off by default
+  WfBuf tops;
+  memset(&tops, 0, sizeof(tops));
+  {
+    const qa_flat_header *h = reinterpret_cast<const qa_flat_header *>(c->hostBlob.data());
+    const qa_instance *inst = QA_BLOB_PTR(qa_instance, c->hostBlob.data(), h->off_instances);
+    std::vector<int> meshes;
+    for (uint32_t k = 0; k < h->num_instances && k < 32; ++k)
+      if (inst[k].obj_type == QA_OBJ_MESH && c->hostMeshes[inst[k].mesh].useWide && c->hostMeshes[inst[k].mesh].wnodeCount > 0 &&
+          std::find(meshes.begin(), meshes.end(), inst[k].mesh) == meshes.end() && meshes.size() < 8)
+        meshes.push_back(inst[k].mesh);
+    const uint32_t budgetNodes = w.topKB * 1024u / 64u;
+    const uint32_t share = meshes.empty() ? 0u : budgetNodes / (uint32_t) meshes.size();
+    uint32_t off = 0;
+    for (int mi : meshes) {
+      const DMesh &dm = c->hostMeshes[mi];
+      const uint32_t cnt = std::min(share, dm.wnodeCount);
+      if (!cnt) continue;
+      tops.topSrc[tops.topCopies] = reinterpret_cast<const uint4 *>(dm.wnodes);
+      tops.topOff[tops.topCopies] = off;
+      tops.topCnt[tops.topCopies] = cnt;
+      for (uint32_t k = 0; k < h->num_instances && k < 32; ++k)
+        if (inst[k].obj_type == QA_OBJ_MESH && inst[k].mesh == mi) { tops.instTopOff[k] = off; tops.instTopCnt[k] = cnt; }
+      off += 4 * cnt;
+      tops.topCopies++;
+    }
+    tops.topVec4 = off;
   }
-  const size_t rays = slots * (1 + b.numLights);
-  const unsigned logicBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * 8, blocks);
-  const unsigned cullBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * 8, (rays + QA_BLOCK - 1) / QA_BLOCK);
-  const unsigned traceBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * w.traceBlocksPerCU, (rays + QA_BLOCK - 1) / QA_BLOCK);
-  const unsigned redoBlocks = (unsigned) std::min<size_t>((size_t) c->numCUs * 2, (rays + QA_BLOCK - 1) / QA_BLOCK);
+  const size_t stackLds = (size_t) ds.stackDepth * QA_BLOCK * sizeof(uint32_t);
+  const size_t traceLds = (size_t) traceStack * QA_BLOCK * sizeof(uint32_t) + (size_t) tops.topVec4 * 16;
+  if (traceLds > 64 * 1024) return Fail(QA_EUNSUPPORTED, "staged trace stage: stacks + tree tops exceed 64 KB of LDS (lower QA_WF_TOP_KB)");
+  // persistent grids: with several groups every stage kernel takes a slice of the chip (2 workgroups per CU by default),
+  // so that kernels of different groups are resident together; a single group takes what fits
+  int perCU = w.traceBlocksPerCU;
+  if (!perCU) {
+    if (G > 1) perCU = 2;
+    else {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) wf_trace, QA_BLOCK, traceLds) != hipSuccess || n < 1) n = 2;
+      perCU = std::min(n, 8);
+    }
+  }
   const uint32_t budget = w.budget;
-  b.refillAt = getenv("QA_WF_REFILL") ? (uint32_t) atoi(getenv("QA_WF_REFILL")) : 16u;
-  const bool dbg = getenv("QA_WF_DEBUG") != nullptr;
-  b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;   // synchronise and report after every stage
+  const bool dbg = getenv("QA_WF_DEBUG") != nullptr;   // synchronise and report after every stage
+  const uint32_t refillAt = getenv("QA_WF_REFILL") ? (uint32_t) atoi(getenv("QA_WF_REFILL")) : 16u;
+
+  // ---- per-group buffers and launch shapes
+  struct Shape { unsigned initBlocks, logicBlocks, cullBlocks, traceBlocks, redoBlocks; };
+  Shape shape[WfHost::kMaxGroups];
+  if (!w.dStats) {
+    HIP_TRY(hipMalloc((void **) &w.dStats, sizeof(WfStats)));
+    HIP_TRY(hipMemset(w.dStats, 0, sizeof(WfStats)));
+    HIP_TRY(hipEventCreateWithFlags(&w.start, hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventRecord(w.start, s));
+  for (int gi = 0; gi < G; ++gi) {
+    Group &g = w.groups[gi];
+    const size_t gtiles = (tiles - (size_t) gi + (size_t) G - 1) / (size_t) G;   // tiles gi, gi + G, ...
+    const size_t slots = gtiles * 64;
+    int rc = EnsureBuffers(c, g, std::max<size_t>(slots, 64), w.numLights, ds.stackDepth, traceStack);
+    if (rc != QA_OK) return rc;
+    WfBuf &b = g.buf;
+    b.n = (uint32_t) slots;
+    b.groupIndex = (uint32_t) gi;
+    b.groupCount = (uint32_t) G;
+    b.numLights = (uint32_t) w.numLights;
+    for (int j = 0; j < QA_WF_MAX_LIGHTS; ++j) b.lightIdx[j] = w.lightIdx[j];
+    memcpy(b.instTopOff, tops.instTopOff, sizeof(b.instTopOff));
+    memcpy(b.instTopCnt, tops.instTopCnt, sizeof(b.instTopCnt));
+    memcpy(b.topSrc, tops.topSrc, sizeof(b.topSrc));
+    memcpy(b.topOff, tops.topOff, sizeof(b.topOff));
+    memcpy(b.topCnt, tops.topCnt, sizeof(b.topCnt));
+    b.topCopies = tops.topCopies;
+    b.topVec4 = tops.topVec4;
+    b.refillAt = refillAt;
+    b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;
+    const size_t rays = slots * (1 + b.numLights);
+    Shape &sh = shape[gi];
+    sh.initBlocks = (unsigned) std::max<size_t>(1, (slots + QA_BLOCK - 1) / QA_BLOCK);
+    const size_t slice = (size_t) c->numCUs * (size_t) perCU;
+    sh.logicBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? slice : (size_t) c->numCUs * 8, sh.initBlocks));
+    sh.cullBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? slice : (size_t) c->numCUs * 8, (rays + QA_BLOCK - 1) / QA_BLOCK));
+    sh.traceBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(slice, (rays + QA_BLOCK - 1) / QA_BLOCK));
+    sh.redoBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) c->numCUs * 2, (rays + QA_BLOCK - 1) / QA_BLOCK));
+    g.finished = slots == 0;
+    HIP_TRY(hipStreamWaitEvent(g.stream, w.start, 0));   // after whatever the caller queued before this frame
+    if (slots) hipLaunchKernelGGL(wf_init, dim3(sh.initBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, b);
+  }
+  HIP_TRY(hipGetLastError());
+
   // every pixel advances by at most one path segment per pass; suspended walks add passes
   const long long maxIter = ((long long) rp.spp_max * (rp.max_bounce + 3) + 4) * 64;
   long long iter = 0;
-  bool finished = false;
-  while (!finished && iter < maxIter) {
-    if (__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) break;   // tasking::signal_stop: unfinished pixels keep ns = 0
-    HIP_TRY(hipMemsetAsync(w.dCtr, 0, kChunk * sizeof(WfCounters), s));
-    for (int i = 0; i < kChunk; ++i, ++iter) {
-      WfCounters *ctr = w.dCtr + i;
-      const uint32_t parity = (uint32_t) (iter & 1);
-      if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, frameCounters, parity);
-      else hipLaunchKernelGGL(wf_logic<false>, dim3(logicBlocks), dim3(QA_BLOCK), 0, s, ds, rp, b, ctr, frameCounters, parity);
-      if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld logic ok\n", iter); }
-      hipLaunchKernelGGL(wf_cull, dim3(cullBlocks), dim3(QA_BLOCK), 0, s, ds, b, ctr);
-      if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld cull ok\n", iter); }
-      hipLaunchKernelGGL(wf_trace, dim3(traceBlocks), dim3(QA_BLOCK), (unsigned) traceLds, s, ds, b, ctr, parity, budget);
-      if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld trace ok\n", iter); }
-      hipLaunchKernelGGL(wf_redo, dim3(redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, s, ds, b, ctr);
-      if (dbg) { HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[wf] pass %lld redo ok\n", iter); }
+  bool allDone = false, stopped = false;
+  while (!allDone && iter < maxIter) {
+    if (__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) { stopped = true; break; }   // tasking::signal_stop: unfinished pixels keep ns = 0
+    for (int gi = 0; gi < G; ++gi) {
+      Group &g = w.groups[gi];
+      if (g.finished) continue;
+      HIP_TRY(hipMemsetAsync(g.dCtr, 0, kChunk * sizeof(WfCounters), g.stream));
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(w.hCtr, w.dCtr, kChunk * sizeof(WfCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // the chains of the groups are issued pass by pass, interleaved, so that their kernels reach the GPU side by side
     for (int i = 0; i < kChunk; ++i) {
-      w.raysClosest += w.hCtr[i].nClosest;
-      w.raysShadow += w.hCtr[i].nShadow;
-      w.jobs += w.hCtr[i].nJobs;
-      w.redo += w.hCtr[i].nRedo;
-      if (w.hCtr[i].active) w.iterations++;
+      const uint32_t parity = (uint32_t) ((iter + i) & 1);
+      for (int gi = 0; gi < G; ++gi) {
+        Group &g = w.groups[gi];
+        if (g.finished) continue;
+        const Shape &sh = shape[gi];
+        WfCounters *ctr = g.dCtr + i;
+        if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
+        else hipLaunchKernelGGL(wf_logic<false>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
+        if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld logic ok\n", gi, iter + i); }
+        hipLaunchKernelGGL(wf_cull, dim3(sh.cullBlocks), dim3(QA_BLOCK), 0, g.stream, ds, g.buf, ctr);
+        if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld cull ok\n", gi, iter + i); }
+        hipLaunchKernelGGL(wf_trace, dim3(sh.traceBlocks), dim3(QA_BLOCK), (unsigned) traceLds, g.stream, ds, g.buf, ctr, parity, budget);
+        if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld trace ok\n", gi, iter + i); }
+        hipLaunchKernelGGL(wf_redo, dim3(sh.redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, g.stream, ds, g.buf, ctr);
+        if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld redo ok\n", gi, iter + i); }
+      }
     }
-    if (w.hCtr[kChunk - 1].active == 0) finished = true;
+    iter += kChunk;
+    HIP_TRY(hipGetLastError());
+    for (int gi = 0; gi < G; ++gi) {
+      Group &g = w.groups[gi];
+      if (g.finished) continue;
+      HIP_TRY(hipMemcpyAsync(g.hCtr, g.dCtr, kChunk * sizeof(WfCounters), hipMemcpyDeviceToHost, g.stream));
+    }
+    allDone = true;
+    for (int gi = 0; gi < G; ++gi) {
+      Group &g = w.groups[gi];
+      if (g.finished) continue;
+      HIP_TRY(hipStreamSynchronize(g.stream));
+      for (int i = 0; i < kChunk; ++i) {
+        w.raysClosest += g.hCtr[i].nClosest;
+        w.raysShadow += g.hCtr[i].nShadow;
+        w.jobs += g.hCtr[i].nJobs;
+        w.redo += g.hCtr[i].nRedo;
+        if (gi == 0 && g.hCtr[i].active) w.iterations++;
+      }
+      if (g.hCtr[kChunk - 1].active == 0) g.finished = true;
+      else allDone = false;
+    }
   }
-  if (!finished && !__atomic_load_n(c->hStop, __ATOMIC_SEQ_CST)) return Fail(QA_EHIP, "staged integrator did not converge (internal error)");
+  // the caller's stream continues after every group
+  for (int gi = 0; gi < G; ++gi) {
+    Group &g = w.groups[gi];
+    HIP_TRY(hipEventRecord(g.done, g.stream));
+    HIP_TRY(hipStreamWaitEvent(s, g.done, 0));
+  }
+  if (!allDone && !stopped) return Fail(QA_EHIP, "staged integrator did not converge (internal error)");
   return QA_OK;
 }

@@ -10,8 +10,8 @@
 // triangle ranges, so a ray that enters a reference leaf - the only place the reference ever tests a triangle -
 // also enters every box above that leaf here (boxes are unions, tests are non-strict and widened by the fp32
 // slack of the reference's inside test).  Inner structure: binned surface-area heuristic, collapsed to four
-// children per node; one node = 128 bytes = four child boxes (SoA) + four child words + the four reference
-// leaf ids (for the order check of shadow hits).
+// children per node, numbered breadth-first; one node = 64 bytes: the four child boxes quantised outwards to 8 bits
+// per plane on the node's own grid, and four child words (DWideNode, qa_scene_dev.h).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -63,9 +63,12 @@ class WideBvhBuilder {
     bin_.clear();
     bin_.reserve(2 * (size_t) n);
     BuildBinary(0, n, 0);
-    // collapse to four children per node
-    out.nodes.reserve(n / 2 + 4);
-    out.rootWord = Collapse(0, 1);
+    // collapse to four children per node, then number breadth-first and quantise
+    tmp_.clear();
+    tmp_.reserve(n / 2 + 4);
+    const uint32_t root = Collapse(0, 1);
+    Finish(root);
+    out.rootWord = 0;   // breadth-first: the root is node 0
   }
 
  private:
@@ -171,7 +174,9 @@ class WideBvhBuilder {
     return id;
   }
 
-  // -> child word of the wide node made from binary node `b` (an inner one)
+  struct TmpNode { float lo[4][3], hi[4][3]; uint32_t child[4]; bool inner[4]; int n; };
+
+  // -> index (in tmp_) of the wide node made from binary node `b` (an inner one)
   uint32_t Collapse(uint32_t b, uint32_t level)
   {
     if (level > out_->depth) out_->depth = level;
@@ -192,28 +197,64 @@ class WideBvhBuilder {
       kids[pick] = bin_[k].left;
       kids[nk++] = bin_[k].right;
     }
-    const uint32_t w = (uint32_t) out_->nodes.size();
-    out_->nodes.push_back(DWideNode{});
-    DWideNode nd;
-    for (int i = 0; i < 4; ++i) {
-      for (int k = 0; k < 3; ++k) { nd.lo[k][i] = 1e30f; nd.hi[k][i] = -1e30f; }   // empty slot: never entered
-      nd.child[i] = QA_DONE;
-      nd.refLeaf[i] = 0;
-    }
+    const uint32_t w = (uint32_t) tmp_.size();
+    tmp_.push_back(TmpNode{});
+    TmpNode nd;
+    nd.n = nk;
+    for (int i = 0; i < 4; ++i) { nd.child[i] = QA_DONE; nd.inner[i] = false; }
     for (int i = 0; i < nk; ++i) {
       const BinNode &c = bin_[kids[i]];
-      for (int k = 0; k < 3; ++k) { nd.lo[k][i] = c.box[k]; nd.hi[k][i] = c.box[3 + k]; }
-      if (c.left == ~0u) {
-        nd.child[i] = ref_[leaves_[c.prim]].data;       // the reference leaf's own word: flag + triangle range
-        nd.refLeaf[i] = leaves_[c.prim];
-      } else {
-        nd.child[i] = Collapse(kids[i], level + 1);
-      }
+      for (int k = 0; k < 3; ++k) { nd.lo[i][k] = c.box[k]; nd.hi[i][k] = c.box[3 + k]; }
+      if (c.left == ~0u) nd.child[i] = ref_[leaves_[c.prim]].data;     // the reference leaf's own word: flag + triangle range
+      else { nd.child[i] = Collapse(kids[i], level + 1); nd.inner[i] = true; }
     }
-    out_->nodes[w] = nd;
+    tmp_[w] = nd;
     return w;
   }
 
+  static float Decode(float origin, float scale, uint32_t q) { return std::fmaf((float) q, scale, origin); }
+
+  // breadth-first numbering + outward quantisation (checked with the very fma the device evaluates)
+  void Finish(uint32_t root)
+  {
+    std::vector<uint32_t> order, newId(tmp_.size(), 0);
+    order.reserve(tmp_.size());
+    order.push_back(root);
+    for (size_t h = 0; h < order.size(); ++h) {
+      const TmpNode &t = tmp_[order[h]];
+      for (int i = 0; i < t.n; ++i) if (t.inner[i]) order.push_back(t.child[i]);
+    }
+    for (size_t i = 0; i < order.size(); ++i) newId[order[i]] = (uint32_t) i;
+    out_->nodes.assign(order.size(), DWideNode{});
+    for (size_t i = 0; i < order.size(); ++i) {
+      const TmpNode &t = tmp_[order[i]];
+      DWideNode &d = out_->nodes[i];
+      for (int k = 0; k < 3; ++k) {
+        float lo = 1e30f, hi = -1e30f;
+        for (int c = 0; c < t.n; ++c) { lo = std::min(lo, t.lo[c][k]); hi = std::max(hi, t.hi[c][k]); }
+        d.origin[k] = lo;
+        int e;
+        const float ext = hi - lo;
+        float scale = 1.17549435e-38f;                              // degenerate extent: any grid will do
+        if (ext > 0) { std::frexp(ext / 255.0f, &e); scale = std::ldexp(1.0f, e); }   // power of two >= ext / 255
+        while (Decode(lo, scale, 255) < hi) scale *= 2.f;
+        d.scale[k] = scale;
+        d.lo[k] = d.hi[k] = 0;
+        for (int c = 0; c < t.n; ++c) {
+          int ql = (int) std::floor((t.lo[c][k] - lo) / scale), qh = (int) std::ceil((t.hi[c][k] - lo) / scale);
+          ql = std::min(std::max(ql, 0), 255);
+          qh = std::min(std::max(qh, 0), 255);
+          while (ql > 0 && Decode(lo, scale, (uint32_t) ql) > t.lo[c][k]) --ql;
+          while (qh < 255 && Decode(lo, scale, (uint32_t) qh) < t.hi[c][k]) ++qh;
+          d.lo[k] |= (uint32_t) ql << (8 * c);
+          d.hi[k] |= (uint32_t) qh << (8 * c);
+        }
+      }
+      for (int c = 0; c < 4; ++c) d.child[c] = (c < t.n) ? (t.inner[c] ? newId[t.child[c]] : t.child[c]) : QA_DONE;
+    }
+  }
+
+  std::vector<TmpNode> tmp_;
   const DNode *ref_;
   uint32_t numRef_;
   WideBvh *out_ = nullptr;

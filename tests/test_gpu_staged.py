@@ -253,6 +253,28 @@ def test_staged_strips_partition_and_determinism(ctx):
     assert np.array_equal(bits(asm), bits(full[0]))
 
 
+@pytest.mark.parametrize("scene", ["trc_scene_tower.xml", "example_project7_object.xml"])
+def test_staged_tile_groups_on_streams_equal_the_megakernel(ctx, scene):
+    """Frames of more than ~4000 tiles are dealt to three groups of interleaved tiles, each driving its own chain of stage
+    kernels on its own stream (qa_wf.hip): same bits and counters as the megakernel, twice in a row."""
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    W, H, spp = 1280, 720, 6
+    ctx.upload_scene(load_scene_blob(scene, size=(W, H)))
+    ctx.set_pipeline("mega")
+    ctx.reset_counters()
+    ref = ctx.render_region((0, 0, W, H), spp)
+    cref = ctx.counters()
+    ctx.set_pipeline("staged")
+    for _ in range(2):
+        ctx.reset_counters()
+        out = ctx.render_region((0, 0, W, H), spp)
+        c = ctx.counters()
+        for a, b in zip(out, ref):
+            assert np.array_equal(bits(a), bits(b))
+        assert c == cref
+
+
 def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
     """QA_PIPE_AUTO: the first large frame is preceded by a timed 4-spp probe of both integrators; whatever it picks, the
     frame equals the megakernel's, and the probe leaves the counters alone."""
