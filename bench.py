@@ -28,6 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialise: see qaray_amd/hip.py
 
 import numpy as np  # noqa: E402
 

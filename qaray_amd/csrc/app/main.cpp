@@ -16,6 +16,7 @@ using namespace qaray_hip;
 
 int main(int argc, char **argv)
 {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the staged integrator's tile groups each want a hardware queue (qa_wf.hip)
   RendererParam param;
   const char *file = nullptr;
   std::string out, root;

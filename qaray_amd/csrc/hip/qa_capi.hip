@@ -689,7 +689,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks < 1) blocks = 1;
 
   // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on a
-  // 4-spp frame of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
+  // short (4 - 16 spp) frame of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
   // the megakernel where shading does) and keeps the answer until the next scene upload.
   bool staged = false;
   if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
@@ -699,7 +699,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
       const size_t pixels = (size_t) tiles * 64;
       if (w.decision < 0 && spp_min == spp_max && spp_max >= 64 && pixels >= 500000 && !pmOn) {
         RenderParams pr = rp;
-        pr.spp_min = pr.spp_max = 4;
+        pr.spp_min = pr.spp_max = std::max(4, std::min(16, spp_max / 16));   // long enough to leave the start-up transient on long frames
         pr.counters = c->dCountersProbe;
         hipEvent_t e0, e1, e2;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
@@ -859,6 +859,9 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
   c->tileOrder = getenv("QA_NO_TILE_ORDER") == nullptr;
   if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
+  if (const char *e = getenv("QA_WF_GATE")) c->wf.gate = (uint32_t) std::max(1, atoi(e));
+  // several tile groups only pay when their streams get hardware queues of their own (4 per process by default)
+  c->wf.numGroups = (getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8) ? 4 : 1;
   if (const char *e = getenv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
   if (const char *e = getenv("QA_WF_TOP_KB")) c->wf.topKB = (uint32_t) std::max(0, atoi(e));
   if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;

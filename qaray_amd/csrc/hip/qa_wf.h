@@ -417,8 +417,10 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
       }
     }
 
-    // ---- 4. camera ray (src/renderers/renderer.cpp:312-328)
-    if (phase == WF_PH_SAMPLE) {
+    // ---- 4. camera ray (src/renderers/renderer.cpp:312-328).  New samples start only in passes whose gate is open
+    // (every few passes, qa_wf.hip): the camera rays of neighbouring pixels then travel and are walked together
+    // instead of trickling into every pass next to incoherent bounce rays, once the pixels' paths have drifted apart.
+    if (phase == WF_PH_SAMPLE && b.gateOpen) {
       const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
       const f3 texpos = F3(hx, hy, 0.f) + F3((float) px.px, (float) px.py, 0.f);
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);

@@ -271,6 +271,7 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
         if (g.finished) continue;
         const Shape &sh = shape[gi];
         WfCounters *ctr = g.dCtr + i;
+        g.buf.gateOpen = ((iter + i) % w.gate) == 0 ? 1u : 0u;
         if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
         else hipLaunchKernelGGL(wf_logic<false>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
         if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld logic ok\n", gi, iter + i); }

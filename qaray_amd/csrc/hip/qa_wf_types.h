@@ -73,6 +73,7 @@ struct WfBuf {
   uint32_t instTopOff[32], instTopCnt[32];
   const uint4 *topSrc[8];
   uint32_t topOff[8], topCnt[8], topCopies, topVec4;
+  uint32_t gateOpen;          // this pass may start new samples (set per pass by the host)
   uint32_t refillAt;          // lanes of a wave that must be out of work before it commits / refills (QA_WF_REFILL)
   uint32_t debug;             // QA_WF_DEBUG bits: 1 = skip the order check
   WfStats *stats;

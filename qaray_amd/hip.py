@@ -6,6 +6,11 @@ import os
 
 import numpy as np
 
+# The staged integrator overlaps the stage kernels of four tile groups on four HIP streams; with the runtime's default of
+# four hardware queues per process those streams (plus the caller's) share queues and their kernels serialise.  Ask for
+# eight before the HIP runtime initialises (it reads the variable at its first call; harmless if it is already up).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("QA_HIP_LIB") or os.path.join(_HERE, "lib", "libqaray_hip.so")  # QA_HIP_LIB: A/B builds
 
