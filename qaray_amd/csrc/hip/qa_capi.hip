@@ -73,7 +73,7 @@ static void SetKernelName(qa_ctx *c)
   else if (w.decision < 0) c->kernelName = std::string(name) + " (staged integrator eligible: decided by a timed probe at the first large frame)";
   else {
     char buf[96];
-    snprintf(buf, sizeof(buf), " (probe: megakernel %.2f ms, staged %.2f ms)", w.probeMs[0], w.probeMs[1]);
+    snprintf(buf, sizeof(buf), " (probe, extrapolated to the frame: megakernel %.0f ms, staged %.0f ms)", w.probeMs[0], w.probeMs[1]);
     c->kernelName = std::string(w.decision == 1 ? staged : name) + buf;
   }
 }
@@ -155,7 +155,8 @@ static int PrepareScene(qa_ctx *c)
   std::vector<std::vector<DNode>> allFNodes(h->num_meshes);     // the library's own trees (qa_fastbvh.h)
   std::vector<std::vector<DTri>> allFTris(h->num_meshes);
   std::vector<std::vector<uint32_t>> allFMap(h->num_meshes);
-  std::vector<WideBvh> allWide(h->num_meshes);                  // 4-wide trees over the reference leaves (qa_widebvh.h)
+  std::vector<WideBvh> allWide(h->num_meshes);                  // 4-wide trees over the triangles (qa_widebvh.h)
+  std::vector<std::vector<DTri>> allWTris(h->num_meshes);       // triangle records in their leaf order
   std::vector<MeshSlack> meshSlack(h->num_meshes, MeshSlack{0.f, 0.f});
   std::vector<std::pair<double, double>> fastCost(h->num_meshes, {0.0, 0.0});   // expected ray cost: reference tree, own tree
   std::vector<float> meshInvH(h->num_meshes, 0.f), meshAbsMax(h->num_meshes, 0.f);
@@ -322,11 +323,27 @@ static int PrepareScene(qa_ctx *c)
         // global-memory scene: the 4-wide tree over the reference leaves, and the inside test's fp32 slack
         if (m.num_faces > 0 && m.num_bvh_nodes > 1 && !(getenv("QA_WIDE") && atoi(getenv("QA_WIDE")) == 0)) {
           try {
-            WideBvhBuilder(dn.data(), m.num_bvh_nodes).Run(allWide[mi]);
-            std::vector<float> ev(9 * (size_t) m.num_faces);
+            std::vector<float> ev(9 * (size_t) m.num_faces), tb(6 * (size_t) m.num_faces);
+            std::vector<unsigned char> skip(m.num_faces, 0);
             for (uint32_t e = 0; e < m.num_faces; ++e) {
               const qa_face &f = faces[elements[e]];
               for (int v = 0; v < 3; ++v) memcpy(&ev[9 * (size_t) e + 3 * v], V + 3 * (size_t) f.v[v], 12);
+              const float *p = &ev[9 * (size_t) e];
+              for (int k = 0; k < 3; ++k) {
+                tb[6 * (size_t) e + k] = std::min(p[k], std::min(p[3 + k], p[6 + k]));
+                tb[6 * (size_t) e + 3 + k] = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+              }
+              skip[e] = !(dt[e].N[0] == dt[e].N[0]);   // degenerate: NaN normal, the inside test never accepts it
+            }
+            // triangles per leaf: 3 (same-box A/B of 1 / 2 / 3 / 4 / 6 / 8: C3 288 / 363 / 373 / 382 / 389 / 371, C5 391 / 612 / 614 / 594 /
+            // 565 / 539 Msamples/s on the megakernel; the staged integrator is flat between 2 and 4)
+            const unsigned wideLeaf = getenv("QA_WIDE_LEAF") ? (unsigned) atoi(getenv("QA_WIDE_LEAF")) : 3u;
+            WideBvhBuilder(tb.data(), skip.data(), m.num_faces, wideLeaf).Run(allWide[mi]);
+            // the triangle records once more in the wide tree's leaf order; the element id rides above the 2-bit axis
+            allWTris[mi].resize(allWide[mi].order.size());
+            for (size_t i = 0; i < allWide[mi].order.size(); ++i) {
+              allWTris[mi][i] = dt[allWide[mi].order[i]];
+              allWTris[mi][i].axis |= allWide[mi].order[i] << 2;
             }
             meshSlack[mi] = ComputeMeshSlack(dt.data(), m.num_faces, ev.data());
           } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
@@ -424,7 +441,7 @@ static int PrepareScene(qa_ctx *c)
       const double diag = std::sqrt((double) (m.bmax[0] - m.bmin[0]) * (m.bmax[0] - m.bmin[0]) + (double) (m.bmax[1] - m.bmin[1]) * (m.bmax[1] - m.bmin[1]) +
                                     (double) (m.bmax[2] - m.bmin[2]) * (m.bmax[2] - m.bmin[2]));
       // needle triangles would widen every box by a sizeable part of the mesh: such a mesh keeps the reference tree
-      dm.useWide = (!allWide[mi].nodes.empty() && meshSlack[mi].nearPad < 0.01 * diag) ? 1u : 0u;
+      dm.useWide = (allWide[mi].rootWord != QA_DONE && meshSlack[mi].nearPad < 0.01 * diag) ? 1u : 0u;
     }
     // the order check tests a leaf's box only: valid when every inner box of the reference tree contains its children's
     for (uint32_t i = 1; i < m.num_bvh_nodes && dm.useWide; ++i) {
@@ -443,6 +460,7 @@ static int PrepareScene(qa_ctx *c)
     if ((rc = DeviceCopy(c, allFTris[mi], &dm.ftris)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, allFMap[mi], &dm.fmap)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, allWide[mi].nodes, &dm.wnodes)) != QA_OK) return rc;
+    if ((rc = DeviceCopy(c, allWTris[mi], &dm.wtris)) != QA_OK) return rc;
   }
 
   // ---- material table (plain colours) -----------------------------------------------------------
@@ -688,8 +706,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
-  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on a
-  // short (4 - 16 spp) frame of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
+  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on
+  // short (4 - 32 spp) frames of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
   // the megakernel where shading does) and keeps the answer until the next scene upload.
   bool staged = false;
   if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
@@ -698,24 +716,37 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     else if (w.mode == 2) {
       const size_t pixels = (size_t) tiles * 64;
       if (w.decision < 0 && spp_min == spp_max && spp_max >= 64 && pixels >= 500000 && !pmOn) {
+        // The staged integrator pays a start-up and drain transient per frame, the megakernel does not: time the staged
+        // one at p and 2p spp, the megakernel at p, and compare the two extrapolated to this frame's spp.
+        const int p = std::max(4, std::min(16, spp_max / 16));
         RenderParams pr = rp;
-        pr.spp_min = pr.spp_max = std::max(4, std::min(16, spp_max / 16));   // long enough to leave the start-up transient on long frames
         pr.counters = c->dCountersProbe;
-        hipEvent_t e0, e1, e2;
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-        HIP_TRY(hipEventRecord(e0, s));
+        hipEvent_t e[4];
+        for (auto &x : e) HIP_TRY(hipEventCreate(&x));
+        HIP_TRY(hipEventRecord(e[0], s));
+        pr.spp_min = pr.spp_max = p;
         rc = RenderStaged(c, ds, pr, s, c->dCountersProbe);
         if (rc != QA_OK) return rc;
-        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventRecord(e[1], s));
+        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
+        pr.spp_min = pr.spp_max = 2 * p;
+        rc = RenderStaged(c, ds, pr, s, c->dCountersProbe);
+        if (rc != QA_OK) return rc;
+        HIP_TRY(hipEventRecord(e[2], s));
+        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
         HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
+        pr.spp_min = pr.spp_max = p;
         hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, pr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e2, s));
-        HIP_TRY(hipEventSynchronize(e2));
-        float msStaged = 0, msMega = 0;
-        HIP_TRY(hipEventElapsedTime(&msStaged, e0, e1));
-        HIP_TRY(hipEventElapsedTime(&msMega, e1, e2));
-        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipEventDestroy(e2);
+        HIP_TRY(hipEventRecord(e[3], s));
+        HIP_TRY(hipEventSynchronize(e[3]));
+        float t1 = 0, t2 = 0, tm = 0;
+        HIP_TRY(hipEventElapsedTime(&t1, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&t2, e[1], e[2]));
+        HIP_TRY(hipEventElapsedTime(&tm, e[2], e[3]));
+        for (auto &x : e) (void) hipEventDestroy(x);
+        const float msStaged = t1 + std::max(0.0f, t2 - t1) * (float) (spp_max - p) / (float) p;
+        const float msMega = tm * (float) spp_max / (float) p;
         w.decision = msStaged < msMega ? 1 : 0;
         w.probeMs[0] = msMega;
         w.probeMs[1] = msStaged;

@@ -386,6 +386,8 @@ __device__ __forceinline__ bool hitTriangleZ(const uint4 q0, const uint4 q1, con
 // triangle passes everything but arrives at exactly the distance already held - the one situation
 // in which the order of the tests decides who wins (hitMesh then repeats the query in the
 // reference's order).
+// PACKED: the record comes from DMesh::wtris (element id above the 2-bit axis).
+template <bool PACKED = false>
 __device__ __forceinline__ bool hitTriangleZTie(const uint4 q0, const uint4 q1, const uint4 q2, const Ray &ray, float &hz, bool &tie)
 {
   const f3 N = F3(asF(q0.x), asF(q0.y), asF(q0.z));
@@ -394,7 +396,7 @@ __device__ __forceinline__ bool hitTriangleZTie(const uint4 q0, const uint4 q1, 
   const float pz = dot(ray.p - A, N);
   const float t = -pz / dz;
   const bool pre = !(qabs(dz) < 1e-7f) && !(t <= QA_BIAS);
-  const uint32_t axis = q2.w;
+  const uint32_t axis = PACKED ? (q2.w & 3u) : q2.w;
   const f3 p = ray.p + ray.d * t;
   const bool ax0 = (axis == 0), ax2 = (axis == 2);
   const float pu = ax0 ? p.y : p.x;
@@ -552,10 +554,10 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
   QA_WIDE_CE(k1, w1, k3, w3)                                  \
   QA_WIDE_CE(k1, w1, k2, w2)
 
-// One walk of the library's 4-wide tree over the reference tree's leaves (qa_widebvh.h).  Boxes are widened by
-// `pad` (folded into two copies of the origin) and tested non-strictly, so every reference leaf the ray can have
-// an accepted hit in is visited; children are entered nearest first.  Leaves are the reference's own (same
-// triangle ranges, element order); `tie` is raised when a triangle passes the inside test at exactly the
+// One walk of the library's 4-wide tree (qa_widebvh.h).  Boxes are widened by `pad` (folded into two copies of the
+// origin) and tested non-strictly, so every triangle the reference's inside test can accept at or before the distance
+// held is tested; children are entered nearest first.  `tris` = DMesh::wtris (leaf order, element id in the axis
+// word); `best` returns the element.  `tie` is raised when a triangle passes the inside test at exactly the
 // distance already held.  closest = false stops at the first accepted triangle.  `stack`: LDS, stride QA_BLOCK,
 // `cap` entries - on overflow `tie` is raised too (the caller then repeats the query on the reference tree).
 __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uint32_t rootWord, const Ray &ray, f3 drcp, float pad,
@@ -583,9 +585,10 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
     const uint32_t first = cur & QA_BVH_OFFSET_MASK;
     for (uint32_t i = 0; i < count; ++i) {
       const uint4 *t = tris + 3 * (size_t) (first + i);
-      if (hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie)) {
+      const uint4 t2 = t[2];
+      if (hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie)) {
         hasHit = true;
-        best = first + i;
+        best = t2.w >> 2;               // element (the reference's triangle order)
         if (!closest) return true;
       }
     }
@@ -666,19 +669,19 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
   if constexpr (STATS) {
     hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
   } else if constexpr (!RES) {
-    // Global-memory meshes: the 4-wide tree over the reference tree's leaves (qa_widebvh.h) - a third of the
-    // dependent node reads - with the answer checked against the reference's rules: the found triangle's leaf must
+    // Global-memory meshes: the library's 4-wide tree (qa_widebvh.h) - a third of the dependent node reads, a fifth
+    // of the triangle tests - with the answer checked against the reference's rules: the found triangle's leaf must
     // pass the reference's strict box test at the found distance (refReaches: then the reference's walk, whose
     // running distance is at least that, reaches the triangle too), and no tie may have been seen.  A miss needs no
-    // check: every reference leaf the ray can have an accepted hit in is visited (boxes are unions of the
-    // reference's leaf boxes, widened by the fp32 slack of its inside test).  Otherwise, and for ray origins so
+    // check: every triangle the reference can accept is tested (boxes are unions of triangle bounds, widened by the
+    // fp32 slack of its inside test).  Otherwise, and for ray origins so
     // far out that the inside test's areas can cancel, the lane walks the reference tree as the reference does.
     const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
     bool redo = true;
     const float hz0 = h.z;
     if (m.useWide && insideCancelReach(m, ray.p)) {
       const float pad = m.nearPad + 1e-6f * (oMax + m.absMax);
-      hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), tris, m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
+      hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), reinterpret_cast<const uint4 *>(m.wtris), m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
       redo = tie;
       if (hasHit && !redo) {
         const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad

@@ -71,7 +71,8 @@ static_assert(sizeof(DMaterial) == 96, "DMaterial must be 6 x 16 bytes");
 // OUTWARDS on the node's own 8-bit grid (scale = a power of two): the search only needs boxes that CONTAIN the
 // reference's leaf boxes, and the traversal is bound by the number of scattered 16-byte accesses, not by arithmetic.
 // Child words: inner = node index (breadth-first numbering: the first nodes of a tree are its top levels, which the
-// staged trace stage keeps in LDS); leaf = the reference leaf's own word (flag + triangle range); QA_DONE = empty.
+// staged trace stage can keep in LDS); leaf = flag + range of DMesh::wtris (the format of the reference's leaf words);
+// QA_DONE = empty.
 struct alignas(64) DWideNode {
   float origin[3];
   float scale[3];
@@ -105,8 +106,9 @@ struct DMesh {
   uint32_t resNormals;
   uint32_t resFNodes, resFTris, resFMap;
   uint32_t gateIsRoot;         // the mesh bounds equal the root box of the reference tree bit for bit
-  // the 4-wide tree over the reference tree's leaves (global-memory scenes, non-counting kernels)
+  // the 4-wide tree over the triangles (qa_widebvh.h; global-memory scenes, non-counting kernels)
   const DWideNode *wnodes;
+  const DTri *wtris;           // the records of `tris` in that tree's leaf order, DTri::axis = axis | element << 2
   uint32_t wrootWord;          // child word of the root
   uint32_t useWide;
   uint32_t wnodeCount;         // nodes of the wide tree

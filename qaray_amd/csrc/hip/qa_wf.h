@@ -701,11 +701,11 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
 // ---------------------------------------------------------------------------------------------
 // wf_trace: persistent waves, one BVH walk (job) per lane, finished lanes refilled from the queue.
 //
-// The walk searches the library's 4-wide tree over the reference tree's leaves (qa_widebvh.h, walkWide of
-// qa_kernel.h cut into rounds): boxes widened by the fp32 slack of the reference's inside test, non-strict tests,
-// nearest child first; leaves are the reference's own, their triangles tested with the reference's arithmetic.
+// The walk searches the library's 4-wide tree (qa_widebvh.h, walkWide of qa_kernel.h cut into rounds): boxes widened
+// by the fp32 slack of the reference's inside test, non-strict tests, nearest child first; leaves hold up to three
+// triangles (DMesh::wtris, leaf order), tested with the reference's arithmetic.
 // A lane is walking (at an inner node or at a leaf), finished, over its step budget, or idle.  Each round the
-// wave runs the body more of its lanes wait for (node step: one 128-byte node, four slab tests; leaf step: the
+// wave runs the body more of its lanes wait for (node step: one 64-byte node, four slab tests; leaf step: the
 // leaf's triangles), so both bodies execute with most lanes enabled.  Once a quarter of the wave is not
 // walking, the finished lanes commit (closest: one 64-bit atomicMin of (distance, instance, triangle); shadow:
 // one atomicAnd), the over-budget lanes write their job back with its stack (it continues in the next pass: a
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     if (k < sc.num_inst && sc.inst[k].obj_type == QA_OBJ_MESH) {
       const DMesh &m = sc.mesh[sc.inst[k].mesh];
       wn = (unsigned long long) m.wnodes;
-      tr = (unsigned long long) m.tris;
+      tr = (unsigned long long) m.wtris;
       nd = (unsigned long long) m.nodes;
       sh = (unsigned long long) m.shade;
       root = m.wrootWord;
@@ -951,8 +951,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
         for (uint32_t i = 0; i < count && !stop; ++i) {
           const uint4 *t = tris + 3 * (size_t) (first + i);
           ++nTri;
-          if (hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie)) {
-            best = first + i;
+          const uint4 t2 = t[2];
+          if (hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie)) {
+            best = t2.w >> 2;               // element (the reference's triangle order)
             stop = anyHit;                  // TraceNodeShadow: the first accepted triangle ends the query
           }
         }

@@ -2,16 +2,18 @@
 // used by qa_scene_upload).
 //
 // The reference searches a mesh with cy::BVH (binary, split at the centre of the longest axis, up to four -
-// sometimes eight - triangles per leaf, src/ext/cyBVH.h:318-421): 30 - 60 dependent node reads per ray on the
-// BASELINE meshes, each a round trip to L2 / HBM.  The closest hit does not depend on the tree it is searched
-// with, as long as (a) every triangle the reference can test is also tested here, and (b) the answer is checked
-// against the reference's own rules afterwards (qa_kernel.h hitMesh, qa_wf.h).  For (a) this tree is built
-// OVER THE REFERENCE TREE'S LEAVES: its primitives are the reference's leaf boxes (bit for bit) with their
-// triangle ranges, so a ray that enters a reference leaf - the only place the reference ever tests a triangle -
-// also enters every box above that leaf here (boxes are unions, tests are non-strict and widened by the fp32
-// slack of the reference's inside test).  Inner structure: binned surface-area heuristic, collapsed to four
-// children per node, numbered breadth-first; one node = 64 bytes: the four child boxes quantised outwards to 8 bits
-// per plane on the node's own grid, and four child words (DWideNode, qa_scene_dev.h).
+// sometimes eight - triangles per leaf, src/ext/cyBVH.h:318-421): 30 - 60 dependent node reads and ~20 triangle
+// tests per ray on the BASELINE meshes.  The closest hit does not depend on the tree it is searched with, as long as
+// (a) every triangle the reference can ACCEPT at or before the distance held is also tested here, and (b) the answer
+// is checked against the reference's own rules afterwards (qa_kernel.h hitMesh, qa_wf.h: the found triangle's leaf
+// in the reference tree must pass the reference's strict box test, no tie may have been seen).  For (a) the boxes of
+// this tree are unions of TRIANGLE bounds (vertex floats, exact), tested non-strictly and widened per ray by the
+// fp32 slack of the reference's inside test (ComputeMeshSlack below): an accepted hit point lies within that slack
+// of its triangle, hence inside every widened box above the triangle, so the walk cannot prune it.
+// Inner structure: binned surface-area heuristic over the triangles down to leaves of at most `leafMax` triangles,
+// collapsed to four children per node, numbered breadth-first; one node = 64 bytes: the four child boxes quantised
+// outwards to 8 bits per plane on the node's own grid, and four child words (DWideNode, qa_scene_dev.h).  The
+// triangles are stored once more in this tree's leaf order (DMesh::wtris), each record carrying its element id.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -24,36 +26,27 @@
 namespace qa {
 
 struct WideBvh {
-  std::vector<DWideNode> nodes;   // [0] = root (when the mesh has more than one reference leaf)
+  std::vector<DWideNode> nodes;   // [0] = root (when the mesh has more than one leaf)
+  std::vector<uint32_t> order;    // position in this tree's leaf order -> element (triangle in the reference's order)
   uint32_t rootWord = QA_DONE;    // child word of the root: inner index, or a leaf word when the mesh is one leaf
-  uint32_t rootLeaf = 0;          // reference leaf id when rootWord is a leaf
   uint32_t depth = 0;             // wide nodes on the longest root-to-leaf path
 };
 
 class WideBvhBuilder {
  public:
-  // ref: the reference tree (DNode, root = 1, children adjacent)
-  WideBvhBuilder(const DNode *ref, uint32_t numRef) : ref_(ref), numRef_(numRef) {}
+  // triBox: 6 floats (min, max) per element; skip[e] != 0 leaves element e out (degenerate: never accepted)
+  WideBvhBuilder(const float *triBox, const unsigned char *skip, uint32_t numElements, uint32_t leafMax)
+      : box_(triBox), skip_(skip), numElements_(numElements), leafMax_(std::min(std::max(leafMax, 1u), QA_BVH_COUNT_MASK + 1u)) {}
 
   void Run(WideBvh &out)
   {
     out_ = &out;
     out.nodes.clear();
     out.depth = 0;
-    // reference leaves reachable from the root
-    std::vector<uint32_t> st;
-    if (numRef_ > 1) st.push_back(1);
-    while (!st.empty()) {
-      const uint32_t id = st.back();
-      st.pop_back();
-      if (ref_[id].data & QA_BVH_LEAF_BIT) { leaves_.push_back(id); continue; }
-      const uint32_t ch = ref_[id].data & QA_BVH_CHILD_MASK;
-      st.push_back(ch + 1);
-      st.push_back(ch);
-    }
-    const uint32_t n = (uint32_t) leaves_.size();
+    out.order.clear();
+    for (uint32_t e = 0; e < numElements_; ++e) if (!skip_ || !skip_[e]) prims_.push_back(e);
+    const uint32_t n = (uint32_t) prims_.size();
     if (n == 0) { out.rootWord = QA_DONE; return; }
-    if (n == 1) { out.rootWord = ref_[leaves_[0]].data; out.rootLeaf = leaves_[0]; return; }
     order_.resize(n);
     for (uint32_t i = 0; i < n; ++i) order_[i] = i;
     cen_.resize(3 * (size_t) n);
@@ -66,14 +59,17 @@ class WideBvhBuilder {
     // collapse to four children per node, then number breadth-first and quantise
     tmp_.clear();
     tmp_.reserve(n / 2 + 4);
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out.order[i] = prims_[order_[i]];
+    if (bin_[0].left == ~0u) { out.rootWord = bin_[0].prim; return; }   // the whole mesh is one leaf
     const uint32_t root = Collapse(0, 1);
     Finish(root);
     out.rootWord = 0;   // breadth-first: the root is node 0
   }
 
  private:
-  struct BinNode { float box[6]; uint32_t left, right; uint32_t prim; };   // leaf: left = right = ~0u
-  const float *Box(uint32_t leafIdx) const { return ref_[leaves_[leafIdx]].box; }
+  struct BinNode { float box[6]; uint32_t left, right; uint32_t prim; };   // leaf: left = right = ~0u, prim = its child word
+  const float *Box(uint32_t primIdx) const { return box_ + 6 * (size_t) prims_[primIdx]; }
 
   static float HalfArea(const float *b)
   {
@@ -94,9 +90,9 @@ class WideBvhBuilder {
     Empty(box);
     for (uint32_t i = 0; i < count; ++i) Grow(box, Box(order_[first + i]));
     memcpy(bin_[id].box, box, sizeof(box));
-    if (count == 1) {
+    if (count <= leafMax_) {
       bin_[id].left = bin_[id].right = ~0u;
-      bin_[id].prim = order_[first];
+      bin_[id].prim = QA_BVH_LEAF_BIT | ((count - 1) << QA_BVH_COUNT_SHIFT) | first;   // range of DMesh::wtris
       return id;
     }
     // binned SAH over the centroid bounds (16 bins per axis); median split when no bin boundary separates
@@ -205,7 +201,7 @@ class WideBvhBuilder {
     for (int i = 0; i < nk; ++i) {
       const BinNode &c = bin_[kids[i]];
       for (int k = 0; k < 3; ++k) { nd.lo[i][k] = c.box[k]; nd.hi[i][k] = c.box[3 + k]; }
-      if (c.left == ~0u) nd.child[i] = ref_[leaves_[c.prim]].data;     // the reference leaf's own word: flag + triangle range
+      if (c.left == ~0u) nd.child[i] = c.prim;
       else { nd.child[i] = Collapse(kids[i], level + 1); nd.inner[i] = true; }
     }
     tmp_[w] = nd;
@@ -255,10 +251,11 @@ class WideBvhBuilder {
   }
 
   std::vector<TmpNode> tmp_;
-  const DNode *ref_;
-  uint32_t numRef_;
+  const float *box_;
+  const unsigned char *skip_;
+  uint32_t numElements_, leafMax_;
   WideBvh *out_ = nullptr;
-  std::vector<uint32_t> leaves_, order_;
+  std::vector<uint32_t> prims_, order_;
   std::vector<float> cen_;
   std::vector<BinNode> bin_;
 };

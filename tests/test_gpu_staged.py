@@ -276,8 +276,9 @@ def test_staged_tile_groups_on_streams_equal_the_megakernel(ctx, scene):
 
 
 def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
-    """QA_PIPE_AUTO: the first large frame is preceded by a timed 4-spp probe of both integrators; whatever it picks, the
-    frame equals the megakernel's, and the probe leaves the counters alone."""
+    """QA_PIPE_AUTO: the first large frame is preceded by timed short frames of both integrators (staged at p and 2p spp,
+    megakernel at p, extrapolated to the frame); whatever it picks, the frame equals the megakernel's, and the probe
+    leaves the counters alone."""
     from qaray_amd.host import load_scene_blob
     ensure_assets()
     W, H, spp = 1280, 720, 64
@@ -287,7 +288,7 @@ def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
     ctx.reset_counters()
     a = ctx.render_region((0, 0, W, H), spp)
     ca = ctx.counters()
-    assert "probe: megakernel" in ctx.kernel_name()
+    assert "extrapolated to the frame: megakernel" in ctx.kernel_name()
     assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
     ctx.set_pipeline("mega")
     ctx.reset_counters()

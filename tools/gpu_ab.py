@@ -20,7 +20,7 @@ variants = []
 for a in args:
     name, _, envs = a.partition(":")
     variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
-KNOBS = ("QA_HIP_LIB", "QA_PIPELINE", "QA_WIDE", "QA_WF_BUDGET", "QA_WF_BLOCKS", "QA_SYNC", "QA_WF_STACK", "QA_WF_REFILL", "QA_WF_TOP_KB", "QA_WF_GROUPS", "QA_WF_GATE")
+KNOBS = ("QA_HIP_LIB", "QA_PIPELINE", "QA_WIDE", "QA_WF_BUDGET", "QA_WF_BLOCKS", "QA_SYNC", "QA_WF_STACK", "QA_WF_REFILL", "QA_WF_TOP_KB", "QA_WF_GROUPS", "QA_WF_GATE", "QA_WIDE_LEAF")
 res = {}
 for name, env in variants:
     for k in KNOBS: os.environ.pop(k, None)
@@ -45,7 +45,7 @@ for name, env in variants:
         if "staged" in ctx.kernel_name():
             st = ctx.staged_stats()
             line += (f" passes {st['passes']} jobs {st['jobs_done']} steps/job {(st['node_steps'] + st['leaf_steps']) / max(1, st['jobs_done']):.1f} "
-                     f"util {st['lane_utilisation']:.3f} susp {st['jobs_suspended']} redone {st['rays_redone']}")
+                     f"tri/job {st['tri_tests'] / max(1, st['jobs_done']):.1f} util {st['lane_utilisation']:.3f} susp {st['jobs_suspended']} redone {st['rays_redone']}")
         print(line, flush=True)
     ctx.close()
 base = variants[0][0]
