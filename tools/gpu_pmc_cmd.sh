@@ -10,13 +10,20 @@ export TMPDIR=/tmp
 cd /tmp
 SCRIPT=$R/$1; shift
 i=0
+# SETS="A B C;D E" replaces the default counter sets (one pass per set)
+if [ -n "$SETS" ]; then IFS=';' read -ra CUSTOM <<< "$SETS"; else CUSTOM=(); fi
+for set in "${CUSTOM[@]}"; do
+  i=$((i+1))
+  timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o r -- python3 $SCRIPT "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
+done
+[ -n "$SETS" ] && PMC_SETS=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" ; do
   i=$((i+1))
-  [ -n "$PMC_SETS" ] && [ $i -gt $PMC_SETS ] && break
-  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o r -- python3 $SCRIPT "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
+  [ -n "$PMC_SETS" ] && { [ "$PMC_SETS" = 0 ] || [ $i -gt $PMC_SETS ]; } && break
+  timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o r -- python3 $SCRIPT "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections
