@@ -893,6 +893,7 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   if (const char *e = getenv("QA_WF_GATE")) c->wf.gate = (uint32_t) std::max(1, atoi(e));
   // several tile groups only pay when their streams get hardware queues of their own (4 per process by default)
   c->wf.numGroups = (getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8) ? 4 : 1;
+  if (const char *e = getenv("QA_WF_REDO_ASYNC")) c->wf.redoAsync = atoi(e) != 0;
   if (const char *e = getenv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
   if (const char *e = getenv("QA_WF_TOP_KB")) c->wf.topKB = (uint32_t) std::max(0, atoi(e));
   if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;

@@ -45,12 +45,15 @@ struct WfHost {
     WfCounters *dCtr = nullptr, *hCtr = nullptr;   // one per iteration of a chunk (device / pinned host)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t logicDone = nullptr, redoDone = nullptr;   // wf_redo runs on WfHost::redoStream beside the pass's cull and trace stages
     bool finished = false;
   };
   static const int kMaxGroups = 8;
   Group groups[kMaxGroups];
   int numGroups = 1;            // 4 when the process has >= 8 hardware queues (GPU_MAX_HW_QUEUES), else 1; QA_WF_GROUPS overrides
   hipEvent_t start = nullptr;
+  hipStream_t redoStream = nullptr;   // shared by the groups
+  bool redoAsync = true;              // QA_WF_REDO_ASYNC=0: wf_redo in the group's own chain
   WfStats *dStats = nullptr;
   // diagnostics of the frames rendered since the last reset
   uint64_t iterations = 0, raysClosest = 0, raysShadow = 0, jobs = 0, redo = 0;

@@ -46,6 +46,8 @@ int EnsureBuffers(qa_ctx *c, Group &g, size_t slots, int lights, uint32_t stackD
     HIP_TRY(hipHostMalloc((void **) &g.hCtr, kChunk * sizeof(WfCounters), hipHostMallocDefault));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.logicDone, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.redoDone, hipEventDisableTiming));
   }
   if (slots <= g.capSlots && lights == g.capLights && stackDepth == g.buf.stackDepth && traceStack == g.buf.traceStack) return QA_OK;
   FreeBuffers(g);
@@ -86,10 +88,14 @@ void FreeStaged(qa_ctx *c)
     if (g.hCtr) (void) hipHostFree(g.hCtr);
     if (g.stream) (void) hipStreamDestroy(g.stream);
     if (g.done) (void) hipEventDestroy(g.done);
+    if (g.logicDone) (void) hipEventDestroy(g.logicDone);
+    if (g.redoDone) (void) hipEventDestroy(g.redoDone);
     g.dCtr = nullptr; g.hCtr = nullptr; g.stream = nullptr; g.done = nullptr;
   }
   if (w.dStats) (void) hipFree(w.dStats);
   if (w.start) (void) hipEventDestroy(w.start);
+  if (w.redoStream) (void) hipStreamDestroy(w.redoStream);
+  w.redoStream = nullptr;
   w.dStats = nullptr;
   w.start = nullptr;
 }
@@ -216,6 +222,11 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     HIP_TRY(hipMemset(w.dStats, 0, sizeof(WfStats)));
     HIP_TRY(hipEventCreateWithFlags(&w.start, hipEventDisableTiming));
   }
+  if (!w.redoStream) HIP_TRY(hipStreamCreateWithFlags(&w.redoStream, hipStreamNonBlocking));
+  // wf_redo (a handful of rays per pass, each a long sequential walk: 60 - 120 us of one lane's latency) only needs this
+  // pass's wf_logic before it and the next pass's wf_logic after it: it runs on a side stream beside wf_cull and wf_trace
+  // (with one group: +4 - 5 %; with four groups the other groups' kernels already fill that time and the extra stream costs 1 - 2 %)
+  const bool redoAsync = w.redoAsync && !dbg && G == 1;
   HIP_TRY(hipEventRecord(w.start, s));
   for (int gi = 0; gi < G; ++gi) {
     Group &g = w.groups[gi];
@@ -275,11 +286,18 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
         if (c->textured) hipLaunchKernelGGL(wf_logic<true>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
         else hipLaunchKernelGGL(wf_logic<false>, dim3(sh.logicBlocks), dim3(QA_BLOCK), 0, g.stream, ds, rp, g.buf, ctr, frameCounters, parity);
         if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld logic ok\n", gi, iter + i); }
+        if (redoAsync) {
+          HIP_TRY(hipEventRecord(g.logicDone, g.stream));
+          HIP_TRY(hipStreamWaitEvent(w.redoStream, g.logicDone, 0));
+          hipLaunchKernelGGL(wf_redo, dim3(sh.redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, w.redoStream, ds, g.buf, ctr);
+          HIP_TRY(hipEventRecord(g.redoDone, w.redoStream));
+        }
         hipLaunchKernelGGL(wf_cull, dim3(sh.cullBlocks), dim3(QA_BLOCK), 0, g.stream, ds, g.buf, ctr);
         if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld cull ok\n", gi, iter + i); }
         hipLaunchKernelGGL(wf_trace, dim3(sh.traceBlocks), dim3(QA_BLOCK), (unsigned) traceLds, g.stream, ds, g.buf, ctr, parity, budget);
         if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld trace ok\n", gi, iter + i); }
-        hipLaunchKernelGGL(wf_redo, dim3(sh.redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, g.stream, ds, g.buf, ctr);
+        if (redoAsync) HIP_TRY(hipStreamWaitEvent(g.stream, g.redoDone, 0));   // before the next wf_logic (and the counters' way back)
+        else hipLaunchKernelGGL(wf_redo, dim3(sh.redoBlocks), dim3(QA_BLOCK), (unsigned) stackLds, g.stream, ds, g.buf, ctr);
         if (dbg) { HIP_TRY(hipStreamSynchronize(g.stream)); fprintf(stderr, "[wf] group %d pass %lld redo ok\n", gi, iter + i); }
       }
     }
