@@ -451,6 +451,11 @@ static int PrepareScene(qa_ctx *c)
         for (int k = 0; k < 3; ++k)
           if (!(nodes[q].box[k] >= nodes[i].box[k] && nodes[q].box[k + 3] <= nodes[i].box[k + 3])) dm.useWide = 0;
     }
+    // QA_SLACK_SCALE is 1 except in the test-only library lib_noslack (qa_scene_dev.h)
+    if (QA_SLACK_SCALE != 1.0f) {
+      dm.nearPad *= QA_SLACK_SCALE;
+      dm.cancelDist = QA_SLACK_SCALE > 0 ? dm.cancelDist / QA_SLACK_SCALE : 1e30f;
+    }
     dm.gateIsRoot = (m.num_bvh_nodes > 1 && memcmp(nodes[1].box, m.bmin, 12) == 0 && memcmp(nodes[1].box + 3, m.bmax, 12) == 0) ? 1u : 0u;
     int rc;
     if ((rc = DeviceCopy(c, dn, &dm.nodes)) != QA_OK) return rc;

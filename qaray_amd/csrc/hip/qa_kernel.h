@@ -680,7 +680,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     bool redo = true;
     const float hz0 = h.z;
     if (m.useWide && insideCancelReach(m, ray.p)) {
-      const float pad = m.nearPad + 1e-6f * (oMax + m.absMax);
+      const float pad = m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
       hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), reinterpret_cast<const uint4 *>(m.wtris), m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
       redo = tie;
       if (hasHit && !redo) {
@@ -711,7 +711,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     // (every point of the ray up to the far side of the bounds lies between the origin and the bounds)
     const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
     const float P = qmax(m.absMax, oMax);
-    const float pad = (1.2e-5f * m.invH) * (P * P) + 1e-6f * P;
+    const float pad = ((QA_SLACK_SCALE * 1.2e-5f) * m.invH) * (P * P) + (QA_SLACK_SCALE * 1e-6f) * P;
     hasHit = walkBVH<true, false>(fnodes, ftris, m.frootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestF, tie, pad);
     // Beyond the mesh bounds a triangle can only be "hit" by cancellation: at a distance D from the
     // triangle the inside test is off by ~64 eps D^2 / (L h) and would have to be off by D / L, i.e.
@@ -722,7 +722,7 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     // D is taken as 1e5 h.  With a hit in hand the question does not arise: D is far beyond the bounds.
     bool redo = tie;
     if (!hasHit && hz0 > meshExit) {
-      const float theta = (1.8e-5f * m.invH) * (oMax + m.absMax) + 2e-5f;   // + the tolerance the normal list was merged with
+      const float theta = ((QA_SLACK_SCALE * 1.8e-5f) * m.invH) * (oMax + m.absMax) + QA_SLACK_SCALE * 2e-5f;   // + the tolerance the normal list was merged with
       const float lim = (theta * theta) * dot(ray.d, ray.d);
       bool parallel = m.numNormals == 0;   // no list (too many distinct normals): never trust a miss
       const float4 *nrm = reinterpret_cast<const float4 *>(mem.img + m.resNormals);

@@ -117,6 +117,14 @@ struct DMesh {
   float cancelDist;            // ray origins farther out than this keep the reference tree
 };
 
+// The widening of the own search trees' boxes and the parallelism / cancellation guards (qa_kernel.h hitMesh, qa_wf.h,
+// qa_widebvh.h) all scale with this factor.  It is 1 in the product; `make hip_noslack` builds a test-only library with
+// 0 (lib_noslack/), with which tests/test_gpu_parity.py shows that the constants matter: without them the own trees lose
+// hits the reference accepts.
+#ifndef QA_SLACK_SCALE
+#define QA_SLACK_SCALE 1.0f
+#endif
+
 #define QA_LANE_SLOTS 6   /* per-lane LDS floats behind the traversal stack: running mean and variance of the pixel */
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
 #define QA_KARG_MESH 4

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
           tris = reinterpret_cast<const uint4 *>(s_tris[k]);
           topNodes = s_top + s_topOff[k];
           topCnt = s_topCnt[k];
-          pad = s_pad[k] + 1e-6f * (qmax(qmax(qabs(lo.x), qabs(lo.y)), qabs(lo.z)) + s_absMax[k]);
+          pad = s_pad[k] + (QA_SLACK_SCALE * 1e-6f) * (qmax(qmax(qabs(lo.x), qabs(lo.y)), qabs(lo.z)) + s_absMax[k]);
           if (my >= nCont) cur = s_root[k];
           steps = 0;
           over = false;

@@ -9,6 +9,8 @@ Tolerances (fp32 radiance, written here as the contract asks):
     multiplications), which moves results by a few ulp: per-image RMSE <= 1e-6 and max abs error
     <= 1e-4 (north_star: RMSE < 1e-4).  sinf/cosf/expf/powf return glibc's bits (tests/test_device_math.py).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -174,6 +176,35 @@ def _write_fuzz_scene(tmp, rng, kind):
     return path
 
 
+def _write_edge_scene(tmp, n, offset):
+    """n x n cells of two isolated axis-aligned right triangles each, modelled `offset` away from the object-space origin
+    (the node's transform moves them back in front of the camera).  Out there a hit point is rounded to ~6e-8 * offset,
+    so the reference's inside test accepts points that far outside a triangle's edges - and outside the (flat) bounding
+    box of the cell's two coplanar triangles, which an own search tree without the slack constants has already pruned."""
+    import os
+    o = float(offset)
+    with open(os.path.join(tmp, "edges.obj"), "w") as f:
+        k = 0
+        for i in range(n):
+            for j in range(n):
+                # (every cell at its own height: the reference never enters a box of zero thickness, and a mesh in one
+                # plane would be invisible to it)
+                x, y, z = o + 2 * i - n, o + 2 * j - n, o + 0.01 * ((7 * i + 3 * j) % 11)
+                for (a, b) in ((x, y), (x + 0.7, y + 0.7)):
+                    f.write("v %.9g %.9g %.9g\nv %.9g %.9g %.9g\nv %.9g %.9g %.9g\n" % (a, b, z, a + 0.6, b, z, a, b + 0.6, z))
+                    f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+                    k += 1
+    xml = """<xml><scene>
+      <object type="obj" name="edges.obj" material="m"><translate x="%.9g" y="%.9g" z="%.9g"/></object>
+      <material type="blinn" name="m"><diffuse r="0.7" g="0.6" b="0.5"/><emission value="0.3"/></material>
+      <light type="point" name="l"><intensity value="60"/><position x="3" y="-8" z="12"/></light>
+    </scene><camera><position x="0.3" y="-0.7" z="%.9g"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="50"/>
+      <width value="128"/><height value="96"/></camera></xml>""" % (-o, -o, -o, 2.2 * n)
+    path = os.path.join(tmp, "edges.xml")
+    open(path, "w").write(xml)
+    return path
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("kind", ["soup", "sheets", "needles", "duplicates"])
 def test_own_search_tree_fuzz(ctx, tmp_path, kind, seed):
@@ -197,6 +228,70 @@ def test_own_search_tree_fuzz(ctx, tmp_path, kind, seed):
     # after its first hit, objects.cpp:342-419, while the kernels return at once - same answer, fewer steps)
     assert (cb["casts_normal"], cb["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
     assert rmse(np.nan_to_num(b[0]), np.nan_to_num(o[0])) <= RMSE_TOL
+
+
+def test_full_baseline_frame_own_tree_equals_reference_walk(ctx):
+    """The whole BASELINE C2 frame at its quoted settings (1920x1080, 512 spp, 1.58e9 casts): the default kernel (own SAH
+    tree + the validation rules of hitMesh) and the counting kernel (the reference's cy::BVH walked as the reference walks
+    it) return the same bits in every pixel, and the same sample / cast counts."""
+    from qaray_amd.host import load_scene_blob
+    W, H, spp = 1920, 1080, 512
+    ctx.upload_scene(load_scene_blob("example_project12_box.xml", size=(W, H)))
+    ctx.reset_counters()
+    a = ctx.render_region((0, 0, W, H), spp)
+    ca = ctx.counters()
+    ctx.reset_counters()
+    b = ctx.render_region((0, 0, W, H), spp, stats=True)
+    cb = ctx.counters()
+    assert ca["samples"] == W * H * spp
+    assert (ca["samples"], ca["casts_normal"], ca["casts_shadow"]) == (cb["samples"], cb["casts_normal"], cb["casts_shadow"])
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+
+
+_NOSLACK_PROBE = r"""
+import sys, tempfile
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from test_gpu_parity import _write_edge_scene
+from qaray_amd.host import load_scene_blob
+from qaray_amd import hip
+ctx = hip.Context(0)
+def differing(blob, w, h, spp, pipeline):
+    ctx.set_pipeline(pipeline)
+    ctx.upload_scene(blob)
+    a = ctx.render_region((0, 0, w, h), spp)
+    b = ctx.render_region((0, 0, w, h), spp, stats=True)
+    return int((a[0].view(np.uint32) != b[0].view(np.uint32)).any(axis=2).sum() + (a[1].view(np.uint32) != b[1].view(np.uint32)).sum())
+tmp = tempfile.mkdtemp()
+edge = load_scene_blob(_write_edge_scene(tmp, 28, 4000.0), size=(512, 384), asset_root=tmp)
+print("RESULT", differing(load_scene_blob("example_project12_box.xml", size=(1920, 1080)), 1920, 1080, 512, "mega"),
+      differing(edge, 512, 384, 16, "mega"), differing(edge, 512, 384, 16, "staged"))
+"""
+
+
+def test_slack_constants_of_the_own_trees_matter():
+    """Negative control for the constants that make the own search trees' answers the reference's (box widening by the
+    fp32 slack of the reference's inside test, parallelism / cancellation guards: qa_kernel.h hitMesh, qa_widebvh.h).
+    `make hip_noslack` builds the library with all of them scaled to zero (QA_SLACK_SCALE=0, test-only).  That build must
+    FAIL the checks the product passes: the full C2 frame (own SAH tree vs reference walk: one cast of 1.58e9 goes
+    wrong) and a mesh of isolated axis-aligned triangles modelled 4000 units from its origin (4-wide tree, megakernel
+    and staged: hits the reference accepts just outside a triangle's box are pruned).  The product library on the same
+    inputs: zero differences (second run below; the C2 frame is the test above)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "qaray_amd", "lib_noslack", "libqaray_hip.so")
+    assert os.path.exists(lib), "lib_noslack is missing: __graft_entry__.build() (make hip_noslack) builds it"
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", _NOSLACK_PROBE, ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]]
+    bad = run({"QA_HIP_LIB": lib})
+    assert bad[0] > 0, "the C2 frame does not notice the missing slack constants"
+    assert bad[1] > 0 and bad[2] > 0, "the far edge mesh does not notice the missing slack constants"
+    good = run({"QA_HIP_LIB": ""})
+    assert good == [0, 0, 0]
 
 
 def test_partition_invariance_and_determinism_full_size(ctx):
