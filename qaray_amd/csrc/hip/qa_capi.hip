@@ -73,7 +73,7 @@ static void SetKernelName(qa_ctx *c)
   else if (w.decision < 0) c->kernelName = std::string(name) + " (staged integrator eligible: decided by a timed probe at the first large frame)";
   else {
     char buf[96];
-    snprintf(buf, sizeof(buf), " (probe, extrapolated to the frame: megakernel %.0f ms, staged %.0f ms)", w.probeMs[0], w.probeMs[1]);
+    snprintf(buf, sizeof(buf), " (probe at %d spp: megakernel %.1f ms, staged %.1f ms)", w.probeSpp, w.probeMs[0], w.probeMs[1]);
     c->kernelName = std::string(w.decision == 1 ? staged : name) + buf;
   }
 }
@@ -681,7 +681,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     if (c->tileOrder) rp.tile_order = c->dOrder;
   }
   rp.stop_flag = c->dStopAlias;
-  rp.counters = c->dCounters;
+  rp.counters = c->wf.probing ? c->dCountersProbe : c->dCounters;
   // Scene::usePhotonMap: once qa_photon_maps_build has run, frames gather from the maps
   const bool pmOn = c->photonReady;
   memset(rp.pm, 0, sizeof(rp.pm));
@@ -711,53 +711,50 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
-  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on
-  // short (4 - 32 spp) frames of this very region the first time a large frame is asked for (staged wins where BVH walks dominate,
-  // the megakernel where shading does) and keeps the answer until the next scene upload.
+  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on a
+  // sample of this very region the first time a large frame is asked for (staged wins where BVH walks dominate, the
+  // megakernel where shading does) and keeps the answer until the next scene upload.
   bool staged = false;
   if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
     WfHost &w = c->wf;
-    if (w.mode == 1) staged = true;
+    if (w.probing) staged = w.probeWhich == 1;
+    else if (w.mode == 1) staged = true;
     else if (w.mode == 2) {
       const size_t pixels = (size_t) tiles * 64;
-      if (w.decision < 0 && spp_min == spp_max && spp_max >= 64 && pixels >= 500000 && !pmOn) {
-        // The staged integrator pays a start-up and drain transient per frame, the megakernel does not: time the staged
-        // one at p and 2p spp, the megakernel at p, and compare the two extrapolated to this frame's spp.
-        const int p = std::max(4, std::min(16, spp_max / 16));
-        RenderParams pr = rp;
-        pr.counters = c->dCountersProbe;
-        hipEvent_t e[4];
+      if (w.decision < 0 && spp_min == spp_max && spp_max >= 128 && pixels >= 500000 && !pmOn) {
+        // Both integrators render 32 spp of this very region, each with its own start-up and drain; the faster one takes
+        // the frame.  Cost: 64 spp-equivalents, once per scene upload (frames below 128 spp are not worth it and take the
+        // megakernel).  Cheaper probes mispredicted: 4 - 16 spp frames extrapolated to the frame's spp miss that staged
+        // passes get slower once the pixels' paths drift apart, and on a sample of the strips both integrators run at
+        // half their full-frame rate (too few pixels in flight for the staged one, a tail of expensive tiles for the
+        // megakernel).
+        const int m = 1;
+        const int ps = 32;
+        hipEvent_t e[3];
         for (auto &x : e) HIP_TRY(hipEventCreate(&x));
-        HIP_TRY(hipEventRecord(e[0], s));
-        pr.spp_min = pr.spp_max = p;
-        rc = RenderStaged(c, ds, pr, s, c->dCountersProbe);
-        if (rc != QA_OK) return rc;
-        HIP_TRY(hipEventRecord(e[1], s));
-        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
-        pr.spp_min = pr.spp_max = 2 * p;
-        rc = RenderStaged(c, ds, pr, s, c->dCountersProbe);
+        float ms[2] = {0, 0};
+        w.probing = true;
+        for (int which = 0; which < 2 && rc == QA_OK; ++which) {   // 0: megakernel, 1: staged
+          w.probeWhich = which;
+          HIP_TRY(hipEventRecord(e[which], s));
+          rc = Render(c, x0, y0, x1, y1, tile_row0, tile_row_step * (which == 0 ? m : 1), ps, ps, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
+        }
+        w.probing = false;
         if (rc != QA_OK) return rc;
         HIP_TRY(hipEventRecord(e[2], s));
-        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
-        pr.spp_min = pr.spp_max = p;
-        hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, pr);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e[3], s));
-        HIP_TRY(hipEventSynchronize(e[3]));
-        float t1 = 0, t2 = 0, tm = 0;
-        HIP_TRY(hipEventElapsedTime(&t1, e[0], e[1]));
-        HIP_TRY(hipEventElapsedTime(&t2, e[1], e[2]));
-        HIP_TRY(hipEventElapsedTime(&tm, e[2], e[3]));
+        HIP_TRY(hipEventSynchronize(e[2]));
+        HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
         for (auto &x : e) (void) hipEventDestroy(x);
-        const float msStaged = t1 + std::max(0.0f, t2 - t1) * (float) (spp_max - p) / (float) p;
-        const float msMega = tm * (float) spp_max / (float) p;
-        w.decision = msStaged < msMega ? 1 : 0;
-        w.probeMs[0] = msMega;
-        w.probeMs[1] = msStaged;
-        HIP_TRY(hipMemsetAsync(d_ns, 0, npix * sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
+        ms[0] *= (float) m;
+        w.decision = ms[1] < ms[0] ? 1 : 0;
+        w.probeMs[0] = ms[0];
+        w.probeMs[1] = ms[1];
+        w.probeSpp = ps;
+        w.probeStep = m;
         SetKernelName(c);
+        // (the tile-order table was rebuilt for the probe's partition and is rebuilt for the frame's by the call below)
+        return Render(c, x0, y0, x1, y1, tile_row0, tile_row_step, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
       }
       staged = w.decision == 1;
     }
@@ -769,13 +766,14 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   HIP_TRY(hipEventRecord(ev.a, s));
   if (staged) {
     // one event pair around the whole frame of the staged integrator (qa_wf.h)
-    rc = RenderStaged(c, ds, rp, s, c->dCounters);
+    rc = RenderStaged(c, ds, rp, s, rp.counters);
     if (rc != QA_OK) { c->freeEvents.push_back(ev); return rc; }
   } else {
     hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(ev.b, s));
+  if (c->wf.probing) { c->freeEvents.push_back(ev); return QA_OK; }   // not part of the frame's kernel time
   c->pending.push_back(ev);
   c->launches++;
   // a caller that never asks for timers or counters must not grow the event list without bound

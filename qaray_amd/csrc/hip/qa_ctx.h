@@ -51,6 +51,8 @@ struct WfHost {
   static const int kMaxGroups = 8;
   Group groups[kMaxGroups];
   int numGroups = 1;            // 4 when the process has >= 8 hardware queues (GPU_MAX_HW_QUEUES), else 1; QA_WF_GROUPS overrides
+  bool probing = false;         // Render() is timing the two integrators on a sample of the region
+  int probeWhich = 0, probeSpp = 0, probeStep = 1;
   hipEvent_t start = nullptr;
   hipStream_t redoStream = nullptr;   // shared by the groups
   bool redoAsync = true;              // QA_WF_REDO_ASYNC=0: wf_redo in the group's own chain

@@ -276,19 +276,18 @@ def test_staged_tile_groups_on_streams_equal_the_megakernel(ctx, scene):
 
 
 def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
-    """QA_PIPE_AUTO: the first large frame is preceded by timed short frames of both integrators (staged at p and 2p spp,
-    megakernel at p, extrapolated to the frame); whatever it picks, the frame equals the megakernel's, and the probe
-    leaves the counters alone."""
+    """QA_PIPE_AUTO: the first large frame (>= 128 spp, >= 0.5 Mpixel) is preceded by timed 32-spp renders by both
+    integrators; whatever it picks, the frame equals the megakernel's, and the probe leaves the counters alone."""
     from qaray_amd.host import load_scene_blob
     ensure_assets()
-    W, H, spp = 1280, 720, 64
+    W, H, spp = 1280, 720, 128
     ctx.upload_scene(load_scene_blob("trc_scene_tower.xml", size=(W, H)))
     ctx.set_pipeline("auto")
     assert "probe" in ctx.kernel_name() and "decided" in ctx.kernel_name()
     ctx.reset_counters()
     a = ctx.render_region((0, 0, W, H), spp)
     ca = ctx.counters()
-    assert "extrapolated to the frame: megakernel" in ctx.kernel_name()
+    assert "probe at 32 spp: megakernel" in ctx.kernel_name()
     assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
     ctx.set_pipeline("mega")
     ctx.reset_counters()
