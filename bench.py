@@ -266,7 +266,7 @@ def main():
                                  "'traffic' when a PMC pass of this kernel and frame is committed under profiles/"},
         }
         if staged:
-            # geometry the trace stage read, from its own counters: 128-byte nodes of the 4-wide tree, 48-byte triangle records
+            # geometry the trace stage read, from its own counters: 64-byte nodes of the 4-wide tree, 48-byte triangle records
             out["roofline"]["geometry_bytes_per_launch"] = staged["geometry_bytes"] / max(launches, 1)
             out["roofline"]["trace_lane_utilisation"] = staged["lane_utilisation"]
             out["roofline"]["staged"] = {k: staged[k] for k in ("passes", "jobs_done", "node_steps", "tri_tests", "rays_redone", "jobs_suspended")}
@@ -279,7 +279,7 @@ def main():
                     if f.endswith("_summary.json"):
                         sj = json.load(open(os.path.join(prof_dir, d, f)))
                         if (sj.get("frame") == [W, H] and sj.get("spp") == args.spp and "hbm_traffic_bytes_per_launch" in sj
-                                and sj.get("kernel_name") == kernel_name and sj.get("scene") == os.path.basename(scene_xml)):
+                                and sj.get("kernel_name") == kernel_name.split(" (")[0] and sj.get("scene") == os.path.basename(scene_xml)):
                             best = (sj, os.path.join("profiles", d, f))
             if best:
                 out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]

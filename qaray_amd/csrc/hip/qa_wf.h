@@ -468,8 +468,11 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
 
 // waves per SIMD the allocator must leave room for: four without textures (+5 - 8 % on the tower / glossy scenes against
 // two); the textured variant spills 167 registers at that budget and is 2 % faster at two
+#ifndef QA_WF_LOGIC_WAVES
+#define QA_WF_LOGIC_WAVES 4
+#endif
 template <bool TEX>
-__global__ __launch_bounds__(QA_BLOCK, TEX ? 2 : 4) void wf_logic(const DScene sc, const RenderParams rp, WfBuf b, WfCounters *ctr, DCounters *frame,
+__global__ __launch_bounds__(QA_BLOCK, TEX ? 2 : QA_WF_LOGIC_WAVES) void wf_logic(const DScene sc, const RenderParams rp, WfBuf b, WfCounters *ctr, DCounters *frame,
                                                      uint32_t parity)
 {
   __shared__ uint32_t s_q[QA_BLOCK / 64][2][QA_WF_RAYQ_CAP];
