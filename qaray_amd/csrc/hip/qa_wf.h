@@ -484,30 +484,78 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? 2 : QA_WF_LOGIC_WAVES) void wf_logi
   qS.buf = s_q[wave][1];
   qS.fill = 0;
   unsigned nLive = 0, nNew = 0, nClosest = 0, nPix = 0, nShadow = 0;   // wave-uniform tallies
+  // Only some of a tile's pixels have work in a given pass (their rays are back, their gate is open) and what they do
+  // differs by an order of magnitude (shading a hit against adding a light term or starting a camera ray): the wave sorts
+  // the slots of its tiles into two LDS lists, "shade" and "other", and runs the slot logic on 64 of one kind at a time
+  // (QA_WF_LOGIC_COMPACT=0: one tile at a time, lane = slot).  The slot logic is the same either way, and a slot's
+  // result does not depend on its neighbours: same bits.
+#ifndef QA_WF_LOGIC_COMPACT
+#define QA_WF_LOGIC_COMPACT 1
+#endif
   const unsigned tiles = b.n / 64, wavesTotal = gridDim.x * (QA_BLOCK / 64);
-  for (unsigned tile = blockIdx.x * (QA_BLOCK / 64) + wave; tile < tiles; tile += wavesTotal) {
-    const unsigned slot = tile * 64 + lane;
-    const WfEmit e = wfLogicSlot<TEX>(sc, rp, b, slot, true);
-    qC.push(e.closest, slot, b.rayq, &ctr->nClosest);
-    for (uint32_t j = 0; j < b.numLights; ++j) qS.push((e.shadow >> j) & 1u, slot | (j << 24), b.rayq + b.n, &ctr->nShadow);
-    for (uint32_t t = 0; t <= b.numLights; ++t) {
-      // rare: straight to the global queue
-      const bool r = (e.redo >> t) & 1u;
-      const unsigned long long mR = __ballot(r);
-      if (!mR) continue;
-      unsigned base = 0;
-      const int leader = __ffsll((long long) mR) - 1;
-      if ((int) lane == leader) base = atomicAdd(&ctr->nRedo, (unsigned) __popcll(mR));
-      base = __shfl(base, leader);
-      if (r) b.redoq[base + __popcll(mR & ((1ull << lane) - 1ull))] = slot | (t << 24);
+#if QA_WF_LOGIC_COMPACT
+  __shared__ uint32_t s_list[QA_BLOCK / 64][2][128];
+  unsigned nList[2] = {0, 0};      // wave-uniform
+#endif
+  for (unsigned tile = blockIdx.x * (QA_BLOCK / 64) + wave;; tile += wavesTotal) {
+    const bool last = tile >= tiles;
+#if QA_WF_LOGIC_COMPACT
+    if (!last) {
+      const unsigned slot = tile * 64 + lane;
+      const uint32_t info = __float_as_uint(b.D[slot].w);
+      const uint32_t phase = WF_INFO_PHASE(info);
+      const bool live = phase != WF_PH_DONE;
+      int cat = -1;                // -1: nothing to do in this pass, 0: a hit to shade, 1: anything else
+      if (live && b.out[slot] == 0 && !(phase == WF_PH_SAMPLE && !b.gateOpen)) {
+        const uint32_t flags = b.redoFlag[slot];
+        cat = (phase == WF_PH_TRACED && !(flags & 0x1Fu) && b.key[slot] != ~0ull) ? 0 : 1;
+      }
+      nLive += (unsigned) __popcll(__ballot(live && cat < 0));
+      for (int c = 0; c < 2; ++c) {
+        const unsigned long long m = __ballot(cat == c);
+        if (cat == c) s_list[wave][c][nList[c] + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        nList[c] += (unsigned) __popcll(m);
+      }
+      wfWaveSync();
     }
-    nLive += (unsigned) __popcll(__ballot(e.live && !e.pixelDone));
-    nNew += (unsigned) __popcll(__ballot(e.newSample));
-    nClosest += (unsigned) __popcll(__ballot(e.closest));
-    nPix += (unsigned) __popcll(__ballot(e.pixelDone));
-    unsigned nsh = __popc(e.shadow);
-    for (int off = 32; off > 0; off >>= 1) nsh += __shfl_down(nsh, off);
-    nShadow += __shfl(nsh, 0);
+    while (nList[0] >= 64 || nList[1] >= 64 || (last && (nList[0] | nList[1]))) {
+      const int c = nList[0] >= 64 ? 0 : (nList[1] >= 64 ? 1 : (nList[0] ? 0 : 1));
+      const unsigned n = min(64u, nList[c]), base = nList[c] - n;
+      const bool have = lane < n;
+      const unsigned slot = have ? s_list[wave][c][base + lane] : 0u;
+      nList[c] = base;
+      wfWaveSync();
+#else
+    if (last) break;
+    {
+      const bool have = true;
+      const unsigned slot = tile * 64 + lane;
+#endif
+      const WfEmit e = wfLogicSlot<TEX>(sc, rp, b, slot, have);
+      qC.push(e.closest, slot, b.rayq, &ctr->nClosest);
+      for (uint32_t j = 0; j < b.numLights; ++j) qS.push((e.shadow >> j) & 1u, slot | (j << 24), b.rayq + b.n, &ctr->nShadow);
+      for (uint32_t t = 0; t <= b.numLights; ++t) {
+        // rare: straight to the global queue
+        const bool r = (e.redo >> t) & 1u;
+        const unsigned long long mR = __ballot(r);
+        if (!mR) continue;
+        unsigned base2 = 0;
+        const int leader = __ffsll((long long) mR) - 1;
+        if ((int) lane == leader) base2 = atomicAdd(&ctr->nRedo, (unsigned) __popcll(mR));
+        base2 = __shfl(base2, leader);
+        if (r) b.redoq[base2 + __popcll(mR & ((1ull << lane) - 1ull))] = slot | (t << 24);
+      }
+      nLive += (unsigned) __popcll(__ballot(e.live && !e.pixelDone));
+      nNew += (unsigned) __popcll(__ballot(e.newSample));
+      nClosest += (unsigned) __popcll(__ballot(e.closest));
+      nPix += (unsigned) __popcll(__ballot(e.pixelDone));
+      unsigned nsh = __popc(e.shadow);
+      for (int off = 32; off > 0; off >>= 1) nsh += __shfl_down(nsh, off);
+      nShadow += __shfl(nsh, 0);
+    }
+#if QA_WF_LOGIC_COMPACT
+    if (last) break;
+#endif
   }
   qC.flush(b.rayq, &ctr->nClosest);
   qS.flush(b.rayq + b.n, &ctr->nShadow);

@@ -253,7 +253,8 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     Shape &sh = shape[gi];
     sh.initBlocks = (unsigned) std::max<size_t>(1, (slots + QA_BLOCK - 1) / QA_BLOCK);
     const size_t slice = (size_t) c->numCUs * (size_t) perCU;
-    sh.logicBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? slice : (size_t) c->numCUs * 8, sh.initBlocks));
+    const size_t logicSlice = getenv("QA_WF_LOGIC_BLOCKS") ? (size_t) c->numCUs * (size_t) atoi(getenv("QA_WF_LOGIC_BLOCKS")) : slice;
+    sh.logicBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? logicSlice : (size_t) c->numCUs * 8, sh.initBlocks));
     sh.cullBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? slice : (size_t) c->numCUs * 8, (rays + QA_BLOCK - 1) / QA_BLOCK));
     sh.traceBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(slice, (rays + QA_BLOCK - 1) / QA_BLOCK));
     sh.redoBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) c->numCUs * 2, (rays + QA_BLOCK - 1) / QA_BLOCK));
