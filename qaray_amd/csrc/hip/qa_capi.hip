@@ -1050,6 +1050,14 @@ int qa_get_counters(qa_ctx *c, qa_counters *out)
   out->bvh_nodes = h.bvh_nodes;
   out->tri_tests = h.tri_tests;
   out->pixels = h.pixels;
+#ifdef QA_STAMPS
+  {
+    const double w = (double) std::max<unsigned long long>(h.stamp[9], 1), k = (double) std::max<unsigned long long>(h.stamp[0], 1);
+    fprintf(stderr, "[stamps] waves %llu, iterations/wave %.0f, cycles/wave %.3e | share of wave time: fetch+start %.3f, closest %.3f (mesh walks %.3f), shade %.3f, "
+            "direct light %.3f (shadow mesh walks %.3f), sample end %.3f, miss branch %.3f, hit before shading %.3f, spawn %.3f\n", h.stamp[9], h.stamp[8] / w, k / w, h.stamp[1] / k, h.stamp[2] / k, h.stamp[3] / k,
+            h.stamp[4] / k, h.stamp[5] / k, h.stamp[6] / k, h.stamp[7] / k, h.stamp[10] / k, h.stamp[11] / k, h.stamp[12] / k);
+  }
+#endif
   return QA_OK;
 }
 int qa_reset_counters(qa_ctx *c)

@@ -110,8 +110,13 @@ __host__ __device__ __forceinline__ float sincosf_one(float y, bool want_cos)
   sincos_f64(x, &ds, &dc);
   return want_cos ? (float) dc : (float) ds;
 }
+#ifdef QA_ABL_FAST_SINCOS   /* ablation builds only (timing what the exact routines cost): never parity */
+__host__ __device__ __forceinline__ float qsinf(float x) { return __builtin_sinf(x); }
+__host__ __device__ __forceinline__ float qcosf(float x) { return __builtin_cosf(x); }
+#else
 __host__ __device__ __forceinline__ float qsinf(float x) { return sincosf_one(x, false); }
 __host__ __device__ __forceinline__ float qcosf(float x) { return sincosf_one(x, true); }
+#endif
 
 // Correctly rounded fallback: Cody-Waite reduction by pi/2 (three-term constant) + Taylor
 // kernels on |r| <= pi/4 in fp64 (truncation error < 3e-14).  Valid for |x| < ~1e5.

@@ -44,6 +44,18 @@ namespace qa {
 #define QA_DX 0.01f            /* DiffRay::dx = dy, src/core/ray.cpp:31-32 */
 #define QA_DONE 0xFFFFFFFFu    /* traversal sentinel (has the leaf bit set, never a real node word) */
 
+#ifdef QA_STAMPS
+#define QA_T(var) const unsigned long long var = __builtin_readcyclecounter();
+#define QA_TACC(dst, since)                                                                                  \
+  {                                                                                                          \
+    const unsigned long long d_ = __builtin_readcyclecounter() - (since);                                    \
+    if ((int) __lane_id() == __ffsll((long long) __ballot(1)) - 1) dst += d_;                                \
+  }
+#else
+#define QA_T(var)
+#define QA_TACC(dst, since)
+#endif
+
 struct Ray { f3 p, d; };
 struct RayDiff { f3 dx, dy; };  // directions of the x / y differential rays (they share the origin)
 
@@ -197,6 +209,27 @@ __device__ __forceinline__ Ray localRay(const DScene &sc, int k, const Ray &r0)
   Ray r = r0;
   for (int q = n - 1; q >= 0; --q) r = toNode(instAt<RES>(sc, chain[q]), r);
   return r;
+}
+
+// The same for the instance loops of global-memory scenes, which visit the nodes in pre-order: the children of a group
+// follow each other, so the group's own local ray is kept from one sibling to the next instead of being rebuilt from
+// the root for every child (five walls in one group: five times).  The chain is evaluated top-down either way - the
+// same operations on the same operands.  (Resident kernels keep localRay: their scenes are flat, and the six registers
+// of the kept ray are what the Cornell-box kernel does not have.)
+struct GroupRay { int node; Ray ray; };
+template <bool RES>
+__device__ __forceinline__ Ray localRayInGroup(const DScene &sc, int k, const Ray &r0, GroupRay &g)
+{
+  if constexpr (RES) return localRay<RES>(sc, k, r0);
+  else {
+    const qa_instance &in = instAt<RES>(sc, k);
+    if (in.depth == 1) return toNode(in, r0);
+    if (in.parent != g.node) {
+      g.ray = localRay<RES>(sc, in.parent, r0);
+      g.node = in.parent;
+    }
+    return toNode(in, g.ray);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -777,6 +810,9 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
 {
   cnt.casts_normal++;
   const Ray r0 = rootRay<RES>(sc, world);
+  GroupRay grp;
+  grp.node = -1;
+  grp.ray = r0;
   bool any = false;
   for (int k = 1; k < sc.num_inst; ++k) {
     const int type = instAt<RES>(sc, k).obj_type;
@@ -784,7 +820,7 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
     Ray r;
     RayDiff rd;
     if (TEX) localRayDiff<RES>(sc, k, world, wd, r, rd);
-    else r = localRay<RES>(sc, k, r0);
+    else r = localRayInGroup<RES>(sc, k, r0, grp);
     bool hit;
     if (type == QA_OBJ_SPHERE) {
       hit = hitSphere(r, h, k, true);
@@ -795,7 +831,9 @@ __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DSce
     } else {
       const DMesh &m = meshAt<RES>(sc, instAt<RES>(sc, k).mesh);
       TriPick pick;
+      QA_T(tm0)
       hit = hitMesh<RES, STATS>(mem, m, r, h, k, true, stack, cnt, pick, sc.stackDepth);
+      QA_TACC(cnt.sl[3], tm0)
       if (TEX && hit && m.hasVT) {
         const uint4 *t = (RES ? mem.img + m.resTris : reinterpret_cast<const uint4 *>(m.tris)) + 3 * (size_t) pick.tri;
         const float *vt = m.vt + 6 * (size_t) pick.tri;
@@ -830,16 +868,21 @@ __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &s
   h.z = t_max;
   h.node = -1;
   const Ray r0 = rootRay<RES>(sc, world);
+  GroupRay grp;
+  grp.node = -1;
+  grp.ray = r0;
   for (int k = 1; k < sc.num_inst; ++k) {
     const int type = instAt<RES>(sc, k).obj_type;
     if (type == QA_OBJ_NONE) continue;
-    const Ray r = localRay<RES>(sc, k, r0);
+    const Ray r = localRayInGroup<RES>(sc, k, r0, grp);
     bool hit;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
     else {
       TriPick pick;
+      QA_T(tm0)
       hit = hitMesh<RES, STATS>(mem, meshAt<RES>(sc, instAt<RES>(sc, k).mesh), r, h, k, false, stack, cnt, pick, sc.stackDepth);
+      QA_TACC(cnt.sl[6], tm0)
     }
     if (hit) return 0.0f;
   }
@@ -1131,7 +1174,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
   const unsigned lane = __lane_id();
 
-  DCounters cnt = {0, 0, 0, 0, 0, 0};
+  DCounters cnt = {};
+#ifdef QA_STAMPS
+  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][13];
+  cnt.sl = s_stamps[threadIdx.x / 64];
+  if (__lane_id() < 13) cnt.sl[__lane_id()] = 0;
+#endif
+  QA_T(tKernel)
   TexTables tt;
   tt.blob = sc.blob;
   tt.texmap = sc.texmap;
@@ -1162,6 +1211,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   bool alive = true, needPixel = true, needSample = false;
 
   for (;;) {
+    QA_T(tA)
     // ---- A. tile fetch: a wave owns one 8x8 pixel tile at a time (lane = pixel).  Rays of one
     // tile are coherent and cost about the same, so background tiles (every ray misses the scene
     // bounds) never share a wave with expensive ones.  One atomic per wave and tile; lanes that
@@ -1236,6 +1286,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       cnt.samples++;
     }
 
+    QA_TACC(cnt.sl[1], tA)
     // ---- C. trace ----------------------------------------------------------------------------
     bool done = false;  // path finished in this iteration
     if (alive && !needPixel && !needSample) {
@@ -1250,9 +1301,12 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       th.uvw = F3(0.5f, 0.5f, 0.5f);   // HitInfo::Init (src/core/hitinfo.cpp:31-42)
       th.duvw0 = th.duvw1 = F3(0, 0, 0);
       th.hasTexture = false;
+      QA_T(tC)
       const bool found = traceClosest<RES, TEX, STATS>(mem, sc, path.ray, pathDiff, h, th, stack, cnt);
+      QA_TACC(cnt.sl[2], tC)
       if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
 
+      QA_T(tM)
       if (!found) {
         // background for camera rays (renderer.cpp:337-341), environment otherwise
         // (MtlBlinn_PhotonMap.cpp:249-251); textured versions: TEX kernel variants
@@ -1265,6 +1319,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         }
         path.L = path.L + path.T * c;
         done = true;
+        QA_TACC(cnt.sl[10], tM)
       } else {
         // ---- D. shade: MtlBlinn_PhotonMap::Shade (MtlBlinn_PhotonMap.cpp:256-500) -----------
         // Beer-Lambert attenuation of everything this hit returns, when the ray arrives from
@@ -1291,7 +1346,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           const f3 V = -path.ray.d;
           const f3 N = h.N;
           const f3 p = h.p;
+          QA_TACC(cnt.sl[11], tM)
+          QA_T(tD)
           const Surface sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, path.bounce, path.fromDiffuse, rng);
+          QA_TACC(cnt.sl[4], tD)
           path.L = path.L + path.T * sf.emission;
           const f3 sampleDiffuse = sf.kd, sampleSpecular = sf.ks;
           const float glossSpec = sf.gloss;
@@ -1310,7 +1368,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
 
           // direct lighting (:481-498)
           if (LIGHTS && !AREA) {
+            QA_T(tL)
             path.L = path.L + path.T * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng);
+            QA_TACC(cnt.sl[5], tL)
           }
           if (AREA && nrec < QA_MAX_PATH) {
             const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, path.T.x, path.T.y, path.T.z,
@@ -1320,6 +1380,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             ++nrec;
           }
 
+          QA_T(tS)
           if (spawn) {
             // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
             path.ray.p = p;
@@ -1333,11 +1394,16 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           } else {
             done = true;
           }
+          QA_TACC(cnt.sl[12], tS)
         }
       }
     }
 
     // ---- E. sample finished: SuperSamplerHalton::Accumulate / Loop (scene.cpp:92-121) ---------
+    QA_T(tE)
+#ifdef QA_STAMPS
+    if (lane == 0) cnt.sl[8] += 1;
+#endif
     if (alive && done) {
       if (AREA) {
         for (int lvl = nrec - 1; lvl >= 0; --lvl) {
@@ -1371,6 +1437,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         needPixel = true;
       }
     }
+    QA_TACC(cnt.sl[7], tE)
   }
 
   // ---- counters: wave reduction, one atomic per wave and counter -----------------------------
@@ -1381,6 +1448,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
     if (lane == 0 && x) atomicAdd(&dst[i], x);
   }
+#ifdef QA_STAMPS
+  if (lane == 0) {
+    cnt.sl[0] = __builtin_readcyclecounter() - tKernel;
+    cnt.sl[9] = 1;
+    for (int i = 0; i < 13; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
+  }
+#endif
 }
 
 }  // namespace qa

@@ -166,6 +166,14 @@ struct DScene {
 
 struct DCounters {
   unsigned long long samples, casts_normal, casts_shadow, bvh_nodes, tri_tests, pixels;
+#ifdef QA_STAMPS
+  // Diagnostic builds (make hip EXTRA=-DQA_STAMPS, tools/gpu_stamps.py): shader-clock cycles of qa_integrate's sections summed
+  // over waves, printed by qa_get_counters: 0 kernel, 1 fetch + sample start, 2 closest-hit queries, 3 of which mesh walks,
+  // 4 shadeSurface, 5 direct light, 6 of which shadow mesh walks, 7 sample end, 8 loop iterations, 9 waves, 10 miss branch,
+  // 11 hit before shading, 12 spawn.
+  unsigned long long stamp[13];
+  unsigned long long *sl;   // device side: the wave's accumulators in LDS (one elected lane adds: a section entered by part of the wave counts in full)
+#endif
 };
 
 // One balanced photon map in HBM: [0] unused, [1..count] the kd-tree in heap order

@@ -702,13 +702,16 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       }
     }
     const Ray r0 = rootRay<false>(sc, w);
+    GroupRay grp;   // the local ray of the group whose children are being visited (localRayInGroup, qa_kernel.h)
+    grp.node = -1;
+    grp.ray = r0;
     // ---- spheres and planes
     int bestK = -1;
     bool occluded = false;
     for (int k = 1; k < sc.num_inst; ++k) {
       const int type = sc.inst[k].obj_type;
       if (type != QA_OBJ_SPHERE && type != QA_OBJ_PLANE) continue;
-      const Ray r = localRay<false>(sc, k, r0);
+      const Ray r = localRayInGroup<false>(sc, k, r0, grp);
       const bool hit = (type == QA_OBJ_SPHERE) ? hitSphere(r, h, k, false) : hitPlane(r, h, k, false);
       // hitSphere / hitPlane update only on a strictly smaller distance: bestK ends as the first instance at h.z
       if (hit) { bestK = k; occluded = !closest; }
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
       if (sc.inst[k].obj_type != QA_OBJ_MESH) continue;
       const DMesh &m = sc.mesh[sc.inst[k].mesh];
       if (m.num_faces == 0) continue;
-      const Ray r = localRay<false>(sc, k, r0);
+      const Ray r = localRayInGroup<false>(sc, k, r0, grp);
       float entry, exit_;
       wfMeshGate(m, r, entry, exit_);
       bool go = valid && !occluded && !exact && !(entry > h.z || entry > exit_);
