@@ -242,6 +242,15 @@ def main():
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         headline = os.path.basename(scene_xml) == "example_project12_box.xml"
         what = next((c["what"] for c in CONFIGS.values() if c["scene"] == os.path.basename(scene_xml)), "probe scene, not a BASELINE config")
+        if staged:
+            limiter = ("critical path of the four stage kernels of a pass (launch ramp + the longest mesh walks while the chip drains), several "
+                       "chains in flight; not HBM bandwidth, not arithmetic (profiles/round02/staged_timeline_16spp.txt, session3_experiments.txt)")
+        elif "RES=1" in kernel_name:
+            limiter = ("latency of the LDS-resident tree walk (53 % of wave time on the Cornell box at 5 waves/SIMD; all correctly rounded div / sqrt "
+                       "removed: +5.5 % only); not HBM bandwidth (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
+        else:
+            limiter = ("mesh walks in global memory at low lane occupancy and the dependent loads of the scene-graph loop; not HBM bandwidth, not "
+                       "arithmetic (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
         out = {
             "metric": "Msamples/s (1 sample = 1 camera path), " + ("Cornell box 1080p@512spp" if headline else f"{os.path.basename(scene_xml)} {W}x{H}@{args.spp}spp"),
             "value": msamples, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,12 +265,13 @@ def main():
                        "casts_per_sample": (casts_n + casts_s) / max(samples, 1)},
             # achieved = ALGORITHMIC queue bytes (casts x 144 B + samples x 24 B) per launch / the launch's
             # duration (HIP events on the launch stream).  That is the contract's figure; it is NOT memory traffic: the
-            # megakernel keeps path state in registers, and both integrators are bound by VALU issue / memory latency.
+            # megakernel keeps path state in registers, and neither integrator is bound by HBM bandwidth or by its arithmetic
+            # (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt): see 'actual_limiter'.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": kernel_name, "kernel_ms_avg": k_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": k_bytes,
-                         "actual_limiter": "VALU issue + memory latency (see profiles/ SQ passes), not HBM bandwidth",
+                         "actual_limiter": limiter,
                          "note": "achieved = (casts x 144 B + samples x 24 B) / launch time, SURVEY.md 8d; measured HBM bytes are in "
                                  "'traffic' when a PMC pass of this kernel and frame is committed under profiles/"},
         }
