@@ -373,7 +373,14 @@ static int PrepareScene(qa_ctx *c)
       allFNodes[mi] = fb.nodes;
       allFMap[mi] = fb.order;
       allFTris[mi].resize(m.num_faces);
-      for (uint32_t i = 0; i < m.num_faces; ++i) allFTris[mi][i] = dt[fb.order[i]];
+      // DTri::axis of the own tree's copies = axis | element << 2 | reference-tree leaf << 17: the walk hands back the
+      // element and its leaf (refReaches) with the accepted record itself instead of through two more dependent reads
+      // (fmap, DTriShade::pad) after it.  Meshes beyond 15 bits of either keep the reference tree (useFast below).
+      for (uint32_t i = 0; i < m.num_faces; ++i) {
+        const uint32_t e = fb.order[i];
+        allFTris[mi][i] = dt[e];
+        allFTris[mi][i].axis = (dt[e].axis & 3u) | ((e & 0x7FFFu) << 2) | ((dsh[e].pad & 0x7FFFu) << 17);
+      }
       if (fb.depth > stackNeed) stackNeed = fb.depth;
       if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
       }
@@ -411,7 +418,7 @@ static int PrepareScene(qa_ctx *c)
     dm.num_nodes = m.num_bvh_nodes;
     dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
     dm.frootData = (m.num_faces && allFNodes[mi].size() > 1) ? allFNodes[mi][1].data : QA_DONE;
-    dm.useFast = (totalFaces <= 512 && m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
+    dm.useFast = (totalFaces <= 512 && m.num_bvh_nodes < 0x8000u && m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
     dm.invH = meshInvH[mi];
     dm.absMax = meshAbsMax[mi];
     {

@@ -29,6 +29,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "qa_device_math.h"
 #include "qa_scene_dev.h"
 #include "qa_seed.h"
@@ -83,17 +85,40 @@ namespace qa {
 // arguments (constant address space: wave-uniform indices become scalar loads into SGPRs, no
 // vector-memory round trip on the critical path of every cast); larger scenes read the tables
 // from global memory.
-template <bool RES>
-__device__ __forceinline__ const qa_instance &instAt(const DScene &sc, int k)
+//
+// The tables in global memory are read through the CONSTANT address space: no kernel writes them, and only then may
+// the compiler turn a wave-uniform index into scalar loads (s_load into SGPRs: lower latency, no VGPRs for the
+// matrices) - through a plain pointer out of DScene it cannot rule out that the frame's stores alias the table and
+// issues one vector (flat) load per lane and field instead.  The record is returned by value; fields that are not
+// used are never loaded.
+template <class T>
+__device__ __forceinline__ T ldTable(const T *p)
 {
-  if constexpr (RES) return sc.instv[k];
-  else return sc.inst[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // dword by dword: a whole-struct copy becomes one wide load, which the compiler keeps in the vector path when its
+  // users are vector ALU operations
+  static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "table records are made of dwords");
+  const __attribute__((address_space(4))) uint32_t *w = (const __attribute__((address_space(4))) uint32_t *) p;
+  T v;
+  uint32_t *d = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = w[i];
+  return v;
+#else
+  return *p;
+#endif
 }
 template <bool RES>
-__device__ __forceinline__ const DMesh &meshAt(const DScene &sc, int k)
+__device__ __forceinline__ std::conditional_t<RES, const qa_instance &, qa_instance> instAt(const DScene &sc, int k)
+{
+  if constexpr (RES) return sc.instv[k];
+  else return ldTable(sc.inst + k);
+}
+template <bool RES>
+__device__ __forceinline__ std::conditional_t<RES, const DMesh &, DMesh> meshAt(const DScene &sc, int k)
 {
   if constexpr (RES) return sc.meshv[k];
-  else return sc.mesh[k];
+  else return ldTable(sc.mesh + k);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -533,12 +558,13 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
     for (uint32_t i = 0; i < count; ++i) {
       if (STATS) cnt.tri_tests++;
       const uint4 *t = tris + 3 * (size_t) (first + i);
+      const uint4 t2 = t[2];
       bool accepted;
-      if constexpr (FAST) accepted = hitTriangleZTie(t[0], t[1], t[2], ray, hz, tie);
-      else accepted = hitTriangleZ(t[0], t[1], t[2], ray, hz);
+      if constexpr (FAST) accepted = hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie);
+      else accepted = hitTriangleZ(t[0], t[1], t2, ray, hz);
       if (accepted) {
         hasHit = true;
-        best = first + i;
+        best = FAST ? (t2.w >> 2) : first + i;   // own tree: element | reference leaf << 15 (DMesh::ftris)
         if (!closest) return true;
       }
     }
@@ -731,7 +757,6 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
   } else {
     const uint4 *fnodes = RES ? mem.img + m.resFNodes : reinterpret_cast<const uint4 *>(m.fnodes);
     const uint4 *ftris = RES ? mem.img + m.resFTris : reinterpret_cast<const uint4 *>(m.ftris);
-    const uint32_t *fmap = RES ? reinterpret_cast<const uint32_t *>(mem.img + m.resFMap) : m.fmap;
     const float hz0 = h.z;
     uint32_t bestF = 0;
     // How far from a triangle can a point be that the reference's inside test still accepts?  The test
@@ -767,8 +792,8 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
       redo = redo || parallel;
     }
     if (hasHit) {
-      bestTri = fmap[bestF];
-      const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad
+      bestTri = bestF & 0x7FFFu;                  // element
+      const uint32_t leaf = bestF >> 15;          // its leaf in the reference tree (the record's word, see DMesh::ftris)
       // closest: the distance just found; any-hit: the fixed t_max (h.z is untouched by walkBVH then... it is
       // set to the accepted distance, so take the saved one)
       redo = redo || !refReaches(nodes, leaf, ray, drcp, fastSlab, closest ? h.z : hz0);
@@ -960,7 +985,7 @@ __device__ __forceinline__ f3 directLight(const SceneMem<RES> mem, const DScene 
   f3 sum = F3(0, 0, 0);
   const float normCoefDI = 1.f / (float) sc.num_lights;
   for (int li = 0; li < sc.num_lights; ++li) {
-    const qa_light &l = sc.light[li];
+    const qa_light l = ldTable(sc.light + li);
     if (l.type == QA_LIGHT_AMBIENT) continue;
     const f3 intensity = illuminate<RES, STATS>(mem, sc, l, p, stack, cnt, rng) * normCoefDI;
     const f3 Ld = normalize(-lightDirection(l, p));

@@ -96,7 +96,7 @@ struct DMesh {
   const float *vt;             // [6 * num_faces] texture vertices per triangle, element order
   // the library's own search tree over the same triangles (qa_fastbvh.h); non-counting kernels walk it
   const DNode *fnodes;         // same node format and numbering rules as `nodes`
-  const DTri *ftris;           // the records of `tris`, in this tree's leaf order
+  const DTri *ftris;           // the records of `tris`, in this tree's leaf order, DTri::axis = axis | element << 2 | reference leaf << 17
   const uint32_t *fmap;        // element of this tree -> element of the reference tree
   uint32_t frootData;
   uint32_t useFast;            // 0: this mesh is searched with the reference tree only
