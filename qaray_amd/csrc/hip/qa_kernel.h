@@ -108,6 +108,29 @@ __device__ __forceinline__ T ldTable(const T *p)
   return *p;
 #endif
 }
+// A pointer that comes out of such a record (DMesh::wnodes, wtris, ...) has no address space the compiler can see, and
+// a load through it is a FLAT load: LDS or global decided per access at run time, and counted on both wait counters,
+// so that it also waits for the LDS traffic of the traversal stack.  Where the pointer can only be global memory the
+// load says so.
+__device__ __forceinline__ uint4 ldGlobal(const uint4 *p);
+// GMEM: the pointer is known to be global memory (non-resident scenes); otherwise a plain load (LDS image or unknown)
+template <bool GMEM>
+__device__ __forceinline__ uint4 ld16(const uint4 *p)
+{
+  if constexpr (GMEM) return ldGlobal(p);
+  else return *p;
+}
+__device__ __forceinline__ uint4 ldGlobal(const uint4 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (through the native vector type: uint4 is a class, and its copy would go back through a generic reference)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = *(const __attribute__((address_space(1))) u32x4 *) p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 template <bool RES>
 __device__ __forceinline__ std::conditional_t<RES, const qa_instance &, qa_instance> instAt(const DScene &sc, int k)
 {
@@ -504,7 +527,7 @@ struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element ord
 // with non-strict box tests, and `tie` is raised when a triangle passes the inside test at exactly
 // the distance already held.  Returns whether a triangle was accepted; best = its element index in
 // the walked tree's order.  closest = false stops at the first accepted triangle.
-template <bool FAST, bool STATS>
+template <bool FAST, bool STATS, bool GMEM = false>
 __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, uint32_t rootData, const Ray &ray, f3 drcp,
                                         bool fastSlab, float &hz, bool closest, uint32_t *stack, DCounters &cnt,
                                         uint32_t &best, bool &tie, float pad = 0.f)
@@ -518,7 +541,7 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
     while (!(cur & QA_BVH_LEAF_BIT)) {
       if (STATS) cnt.bvh_nodes++;
       const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
-      const uint4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
+      const uint4 a0 = ld16<GMEM>(pair), a1 = ld16<GMEM>(pair + 1), b0 = ld16<GMEM>(pair + 2), b1 = ld16<GMEM>(pair + 3);
       float entry0, exit0, entry1, exit1;
       const f3 min0 = F3(asF(a0.x), asF(a0.y), asF(a0.z)), max0 = F3(asF(a0.w), asF(a1.x), asF(a1.y));
       const f3 min1 = F3(asF(b0.x), asF(b0.y), asF(b0.z)), max1 = F3(asF(b0.w), asF(b1.x), asF(b1.y));
@@ -558,10 +581,10 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
     for (uint32_t i = 0; i < count; ++i) {
       if (STATS) cnt.tri_tests++;
       const uint4 *t = tris + 3 * (size_t) (first + i);
-      const uint4 t2 = t[2];
+      const uint4 t2 = ld16<GMEM>(t + 2);
       bool accepted;
-      if constexpr (FAST) accepted = hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie);
-      else accepted = hitTriangleZ(t[0], t[1], t2, ray, hz);
+      if constexpr (FAST) accepted = hitTriangleZTie<true>(ld16<GMEM>(t), ld16<GMEM>(t + 1), t2, ray, hz, tie);
+      else accepted = hitTriangleZ(ld16<GMEM>(t), ld16<GMEM>(t + 1), t2, ray, hz);
       if (accepted) {
         hasHit = true;
         best = FAST ? (t2.w >> 2) : first + i;   // own tree: element | reference leaf << 15 (DMesh::ftris)
@@ -630,7 +653,7 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
   while (cur != QA_DONE) {
     while (!(cur & QA_BVH_LEAF_BIT)) {
       const uint4 *nd = wn + 4 * (size_t) cur;
-      const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
       QA_WIDE_NODE(q0, q1, q2, q3)
       // nearest child next, the others stacked farthest first
       if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
@@ -644,8 +667,8 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
     const uint32_t first = cur & QA_BVH_OFFSET_MASK;
     for (uint32_t i = 0; i < count; ++i) {
       const uint4 *t = tris + 3 * (size_t) (first + i);
-      const uint4 t2 = t[2];
-      if (hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie)) {
+      const uint4 t2 = ldGlobal(t + 2);
+      if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, ray, hz, tie)) {
         hasHit = true;
         best = t2.w >> 2;               // element (the reference's triangle order)
         if (!closest) return true;
@@ -677,10 +700,11 @@ __device__ __forceinline__ bool insideCancelReach(const DMesh &m, f3 o)
 // LEAF's box passes the strict test against `limit`, every node above it does.  `limit` is the final
 // hit distance for a closest-hit query (the distance held earlier can only be larger: sufficient),
 // the fixed t_max for an any-hit query (exact).  DTriShade::pad holds an element's leaf id.
+template <bool GMEM = false>
 __device__ __forceinline__ bool refReaches(const uint4 *nodes, uint32_t leaf, const Ray &ray, f3 drcp, bool fastSlab, float limit)
 {
   if (leaf <= 1) return true;   // the root is entered unconditionally (the mesh bounds were tested by the caller)
-  const uint4 n0 = nodes[2 * (size_t) leaf], n1 = nodes[2 * (size_t) leaf + 1];
+  const uint4 n0 = ld16<GMEM>(nodes + 2 * (size_t) leaf), n1 = ld16<GMEM>(nodes + 2 * (size_t) leaf + 1);
   float entry, exit_;
   const f3 bmin = F3(asF(n0.x), asF(n0.y), asF(n0.z)), bmax = F3(asF(n0.w), asF(n1.x), asF(n1.y));
   if (fastSlab) boxEntryExitFast(ray, drcp, bmin, bmax, entry, exit_);
@@ -743,14 +767,14 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
       hasHit = walkWide(reinterpret_cast<const uint4 *>(m.wnodes), reinterpret_cast<const uint4 *>(m.wtris), m.wrootWord, ray, drcp, pad, h.z, closest, stack, stackCap, bestTri, tie);
       redo = tie;
       if (hasHit && !redo) {
-        const uint32_t leaf = shade[3 * (size_t) bestTri + 2].w;   // DTriShade::pad
-        redo = !refReaches(nodes, leaf, ray, drcp, fastSlab, closest ? h.z : hz0);
+        const uint32_t leaf = ldGlobal(shade + 3 * (size_t) bestTri + 2).w;   // DTriShade::pad
+        redo = !refReaches<true>(nodes, leaf, ray, drcp, fastSlab, closest ? h.z : hz0);
       }
     }
     if (redo) {
       h.z = hz0;
       tie = false;
-      hasHit = walkBVH<false, false>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
+      hasHit = walkBVH<false, false, true>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
     }
   } else if (!m.useFast) {
     hasHit = walkBVH<false, STATS>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, closest, stack, cnt, bestTri, tie);
@@ -808,11 +832,11 @@ __device__ __forceinline__ bool hitMesh(const SceneMem<RES> mem, const DMesh &m,
     float ba = 0, bb = 0;
     {
       const uint4 *t = tris + 3 * (size_t) bestTri;
-      triangleDetails(t[0], t[1], t[2], ray, h, ba, bb);
+      triangleDetails(ld16<!RES>(t), ld16<!RES>(t + 1), ld16<!RES>(t + 2), ray, h, ba, bb);
     }
     // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
     const uint4 *s = shade + 3 * (size_t) bestTri;
-    const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
+    const uint4 s0 = ld16<!RES>(s), s1 = ld16<!RES>(s + 1), s2 = ld16<!RES>(s + 2);
     const float bc = 1.f - ba - bb;
     const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)),
              n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));

@@ -127,12 +127,12 @@ __device__ __forceinline__ bool wfHitDetails(const DScene &sc, int k, uint32_t t
   } else {
     const DMesh &m = sc.mesh[in.mesh];
     const uint4 *t = reinterpret_cast<const uint4 *>(m.tris) + 3 * (size_t) tri;
-    const uint4 q0 = t[0], q1 = t[1], q2 = t[2];
+    const uint4 q0 = ldGlobal(t), q1 = ldGlobal(t + 1), q2 = ldGlobal(t + 2);
     float ba = 0, bb = 0;
     h.z = z;
     triangleDetails(q0, q1, q2, r, h, ba, bb);
     const uint4 *s = reinterpret_cast<const uint4 *>(m.shade) + 3 * (size_t) tri;
-    const uint4 s0 = s[0], s1 = s[1], s2 = s[2];
+    const uint4 s0 = ldGlobal(s), s1 = ldGlobal(s + 1), s2 = ldGlobal(s + 2);
     const float bc = 1.f - ba - bb;
     const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)), n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));
     h.N = (n0 * ba + n1 * bb) + n2 * bc;
@@ -143,7 +143,7 @@ __device__ __forceinline__ bool wfHitDetails(const DScene &sc, int k, uint32_t t
       const uint32_t leaf = s2.w;   // DTriShade::pad: the reference-tree leaf that holds this element
       const f3 drcp = F3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
       const bool nearZero = qabs(r.d.x) < 1e-7f || qabs(r.d.y) < 1e-7f || qabs(r.d.z) < 1e-7f;
-      orderOk = refReaches(reinterpret_cast<const uint4 *>(m.nodes), leaf, r, drcp, !nearZero, z);
+      orderOk = refReaches<true>(reinterpret_cast<const uint4 *>(m.nodes), leaf, r, drcp, !nearZero, z);
       if (leaf <= 1 || !m.gateIsRoot) {
         float gEntry, gExit;
         wfMeshGate(m, r, gEntry, gExit);
@@ -364,7 +364,7 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
             for (uint32_t j = 0; j < b.numLights; ++j) {
               float4 sh;
               f3 contrib;
-              wfLight(sc, sc.light[b.lightIdx[j]], p, N, V, sf.kd, sf.ks, sf.gloss, sh, contrib);
+              wfLight(sc, ldTable(sc.light + b.lightIdx[j]), p, N, V, sf.kd, sf.ks, sf.gloss, sh, contrib);
               b.SH[(size_t) j * b.n + slot] = sh;
               b.C[(size_t) j * b.n + slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
             }
@@ -584,7 +584,7 @@ __device__ __forceinline__ bool wfMeshSearch(const DMesh &m, const Ray &ray, flo
   if (entry > hz || entry > meshExit) return false;
   if (m.num_faces == 0) return false;
   bool tie = false;
-  return walkBVH<false, false>(reinterpret_cast<const uint4 *>(m.nodes), reinterpret_cast<const uint4 *>(m.tris), m.rootData, ray, drcp,
+  return walkBVH<false, false, true>(reinterpret_cast<const uint4 *>(m.nodes), reinterpret_cast<const uint4 *>(m.tris), m.rootData, ray, drcp,
                                fastSlab, hz, closest, stack, cnt, bestTri, tie);
 }
 
@@ -598,14 +598,14 @@ __device__ __forceinline__ unsigned long long wfExactClosest(const DScene &sc, c
   uint32_t bestTri = 0;
   const Ray r0 = rootRay<false>(sc, world);
   for (int k = 1; k < sc.num_inst; ++k) {
-    const int type = sc.inst[k].obj_type;
+    const int type = instAt<false>(sc, k).obj_type;
     if (type == QA_OBJ_NONE) continue;
     const Ray r = localRay<false>(sc, k, r0);
     bool hit;
     uint32_t tri = 0;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
-    else hit = wfMeshSearch(sc.mesh[sc.inst[k].mesh], r, h.z, true, stack, tri, cnt);
+    else hit = wfMeshSearch(meshAt<false>(sc, instAt<false>(sc, k).mesh), r, h.z, true, stack, tri, cnt);
     if (hit) { bestK = k; bestTri = tri; }
   }
   return bestK < 0 ? ~0ull : wfKey(h.z, bestK, bestTri);
@@ -619,14 +619,14 @@ __device__ __forceinline__ bool wfExactOccluded(const DScene &sc, const Ray &wor
   h.node = -1;
   const Ray r0 = rootRay<false>(sc, world);
   for (int k = 1; k < sc.num_inst; ++k) {
-    const int type = sc.inst[k].obj_type;
+    const int type = instAt<false>(sc, k).obj_type;
     if (type == QA_OBJ_NONE) continue;
     const Ray r = localRay<false>(sc, k, r0);
     bool hit;
     uint32_t tri = 0;
     if (type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
     else if (type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
-    else hit = wfMeshSearch(sc.mesh[sc.inst[k].mesh], r, h.z, false, stack, tri, cnt);
+    else hit = wfMeshSearch(meshAt<false>(sc, instAt<false>(sc, k).mesh), r, h.z, false, stack, tri, cnt);
     if (hit) return true;
   }
   return false;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
     int bestK = -1;
     bool occluded = false;
     for (int k = 1; k < sc.num_inst; ++k) {
-      const int type = sc.inst[k].obj_type;
+      const int type = instAt<false>(sc, k).obj_type;
       if (type != QA_OBJ_SPHERE && type != QA_OBJ_PLANE) continue;
       const Ray r = localRayInGroup<false>(sc, k, r0, grp);
       const bool hit = (type == QA_OBJ_SPHERE) ? hitSphere(r, h, k, false) : hitPlane(r, h, k, false);
@@ -721,8 +721,9 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
     unsigned njobs = 0;
     bool exact = false;
     for (int k = 1; k < sc.num_inst; ++k) {
-      if (sc.inst[k].obj_type != QA_OBJ_MESH) continue;
-      const DMesh &m = sc.mesh[sc.inst[k].mesh];
+      const qa_instance ik = instAt<false>(sc, k);
+      if (ik.obj_type != QA_OBJ_MESH) continue;
+      const DMesh m = meshAt<false>(sc, ik.mesh);
       if (m.num_faces == 0) continue;
       const Ray r = localRayInGroup<false>(sc, k, r0, grp);
       float entry, exit_;
@@ -848,9 +849,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
             Ray ray;
             ray.p = lo;
             ray.d = ld;
-            const uint32_t leaf = reinterpret_cast<const uint4 *>(s_shade[k])[3 * (size_t) best + 2].w;
+            const uint32_t leaf = ldGlobal(reinterpret_cast<const uint4 *>(s_shade[k]) + 3 * (size_t) best + 2).w;
             const bool nearZero = qabs(ld.x) < 1e-7f || qabs(ld.y) < 1e-7f || qabs(ld.z) < 1e-7f;
-            if (refReaches(reinterpret_cast<const uint4 *>(s_nodes[k]), leaf, ray, drcp, !nearZero, hz0)) atomicAnd(&b.vis[slot], ~(1u << (type - 1u)));
+            if (refReaches<true>(reinterpret_cast<const uint4 *>(s_nodes[k]), leaf, ray, drcp, !nearZero, hz0)) atomicAnd(&b.vis[slot], ~(1u << (type - 1u)));
             else flag = true;
           }
         }
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
           ++nTop;
         } else {
           const uint4 *nd = wn + 4 * (size_t) cur;
-          q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+          q0 = ldGlobal(nd); q1 = ldGlobal(nd + 1); q2 = ldGlobal(nd + 2); q3 = ldGlobal(nd + 3);
         }
 #ifdef QA_WF_NOSORT
         float k0, k1, k2, k3;
@@ -1005,8 +1006,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
         for (uint32_t i = 0; i < count && !stop; ++i) {
           const uint4 *t = tris + 3 * (size_t) (first + i);
           ++nTri;
-          const uint4 t2 = t[2];
-          if (hitTriangleZTie<true>(t[0], t[1], t2, ray, hz, tie)) {
+          const uint4 t2 = ldGlobal(t + 2);
+          if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, ray, hz, tie)) {
             best = t2.w >> 2;               // element (the reference's triangle order)
             stop = anyHit;                  // TraceNodeShadow: the first accepted triangle ends the query
           }
