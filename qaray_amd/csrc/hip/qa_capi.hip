@@ -905,7 +905,6 @@ int qa_ctx_create(int device_id, qa_ctx **out)
   c->wf.numGroups = (getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8) ? 4 : 1;
   if (const char *e = getenv("QA_WF_REDO_ASYNC")) c->wf.redoAsync = atoi(e) != 0;
   if (const char *e = getenv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
-  if (const char *e = getenv("QA_WF_TOP_KB")) c->wf.topKB = (uint32_t) std::max(0, atoi(e));
   if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
   if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {

@@ -60,7 +60,6 @@ struct WfHost {
   // diagnostics of the frames rendered since the last reset
   uint64_t iterations = 0, raysClosest = 0, raysShadow = 0, jobs = 0, redo = 0;
   int traceBlocksPerCU = 0;     // QA_WF_BLOCKS: workgroups per CU of every stage kernel of one group (0 = 2 with several groups, what fits with one)
-  uint32_t topKB = 0;           // KB of LDS for the top levels of the wide trees in wf_trace (QA_WF_TOP_KB); measured slower, off
   uint32_t gate = 1;            // new samples start every gate-th pass (QA_WF_GATE).  2 was worth +50 % with the first trace stage; since the
                                 // 4-wide tree over triangles and the scalar / global table reads it is equal on long frames and 4 - 10 % behind on short ones
   uint32_t stackCap = 24;       // LDS stack entries per lane of wf_trace (QA_WF_STACK)

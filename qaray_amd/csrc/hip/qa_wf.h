@@ -769,7 +769,8 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
 // What makes the answers the reference's: wf_logic's order check of the winning hit (wfHitDetails); here, a tie
 // (a second triangle passing the inside test at exactly the held distance), a full stack, and a shadow hit
 // whose reference leaf fails the strict test against the ray's t_max all send the ray to wf_redo.
-// Dynamic LDS: the lanes' traversal stacks.
+// Dynamic LDS: the lanes' traversal stacks.  (Serving the top 85 - 340 nodes of every tree from LDS was 10 % slower and is gone:
+// profiles/round02/staged_experiments.txt.)
 // ---------------------------------------------------------------------------------------------
 #ifndef QA_WF_TRACE_WAVES
 #define QA_WF_TRACE_WAVES 5
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
 {
   extern __shared__ uint4 s_dyn[];
   __shared__ unsigned long long s_wnodes[32], s_tris[32], s_nodes[32], s_shade[32];
-  __shared__ uint32_t s_root[32], s_topOff[32], s_topCnt[32];
+  __shared__ uint32_t s_root[32];
   __shared__ float s_pad[32], s_absMax[32];
   if (threadIdx.x < 32) {
     const int k = (int) threadIdx.x;
@@ -806,15 +807,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     s_root[k] = root;
     s_pad[k] = pad;
     s_absMax[k] = am;
-    s_topOff[k] = b.instTopOff[k];
-    s_topCnt[k] = b.instTopCnt[k];
   }
   uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn) + threadIdx.x;   // entry s at stack[s * QA_BLOCK]
   const uint32_t cap = b.traceStack;
-  // the top levels of the trees: LDS behind the stacks
-  uint4 *s_top = s_dyn + (size_t) cap * (QA_BLOCK / 4);
-  for (uint32_t c = 0; c < b.topCopies; ++c)
-    for (uint32_t i = threadIdx.x; i < 4 * b.topCnt[c]; i += QA_BLOCK) s_top[b.topOff[c] + i] = b.topSrc[c][i];
   __syncthreads();
   const unsigned lane = __lane_id();
   const unsigned nCont = min(b.contCount[parity], b.contCap), nNew = min(ctr->nJobs, b.jobCap);
@@ -825,8 +820,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
   f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), drcp = F3(0, 0, 1);
   float hz = 0.f, hz0 = 0.f, pad = 0.f;
   uint32_t bits = 0, best = QA_WF_NOBEST, cur = QA_DONE, sp = 0, steps = 0;
-  const uint4 *wn = nullptr, *tris = nullptr, *topNodes = s_top;
-  uint32_t topCnt = 0, nTop = 0;
+  const uint4 *wn = nullptr, *tris = nullptr;
   uint32_t rNext = 0, rEnd = 0;                       // the wave's reserved range of job indices (wave-uniform)
   uint32_t nNode = 0, nLeaf = 0, nTri = 0, nJobsDone = 0, nSusp = 0, nFlag = 0;
   unsigned long long nSlots = 0, nRounds = 0;
@@ -925,8 +919,6 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
           const uint32_t k = bits >> 27;
           wn = reinterpret_cast<const uint4 *>(s_wnodes[k]);
           tris = reinterpret_cast<const uint4 *>(s_tris[k]);
-          topNodes = s_top + s_topOff[k];
-          topCnt = s_topCnt[k];
           pad = s_pad[k] + (QA_SLACK_SCALE * 1e-6f) * (qmax(qmax(qabs(lo.x), qabs(lo.y)), qabs(lo.z)) + s_absMax[k]);
           if (my >= nCont) cur = s_root[k];
           steps = 0;
@@ -939,44 +931,17 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
     }
 
     // ---- one round: the body more lanes wait for
-#ifndef QA_WF_IFIF
-#define QA_WF_IFIF 0     /* 1: every round runs the node body and then the leaf body (every walking lane advances) */
-#endif
+    // (running both bodies every round, and picking out only the nearest child instead of sorting all four, were
+    // measured: 4 % slower / neutral, profiles/round02/staged_experiments.txt)
     const bool atInner = have && !over && !(cur & QA_BVH_LEAF_BIT);
-#if QA_WF_IFIF
-    const int nI = __popcll(__ballot(atInner));
-    if (nI > 0) {
-#else
     const bool atLeaf = have && !over && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE;
     const int nI = __popcll(__ballot(atInner)), nL = __popcll(__ballot(atLeaf));
     if (nI >= nL && nI > 0) {
-#endif
       if (atInner) {
         const f3 pLo = lo + F3(pad, pad, pad), pHi = lo - F3(pad, pad, pad);
-        // the top levels of every tree sit in LDS (breadth-first numbering: node index < topCnt), the rest in global memory
-        uint4 q0, q1, q2, q3;
-        if (cur < topCnt) {
-          const uint4 *nd = topNodes + 4 * (size_t) cur;
-          q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
-          ++nTop;
-        } else {
-          const uint4 *nd = wn + 4 * (size_t) cur;
-          q0 = ldGlobal(nd); q1 = ldGlobal(nd + 1); q2 = ldGlobal(nd + 2); q3 = ldGlobal(nd + 3);
-        }
-#ifdef QA_WF_NOSORT
-        float k0, k1, k2, k3;
-        uint32_t w0 = q3.x, w1 = q3.y, w2 = q3.z, w3 = q3.w;
-        QA_WIDE_CHILD(k0, w0, 0)
-        QA_WIDE_CHILD(k1, w1, 1)
-        QA_WIDE_CHILD(k2, w2, 2)
-        QA_WIDE_CHILD(k3, w3, 3)
-        // only the nearest child is picked out (three compare-exchanges instead of five); the rest keep their order
-        QA_WIDE_CE(k0, w0, k1, w1)
-        QA_WIDE_CE(k0, w0, k2, w2)
-        QA_WIDE_CE(k0, w0, k3, w3)
-#else
+        const uint4 *nd = wn + 4 * (size_t) cur;
+        const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
         QA_WIDE_NODE(q0, q1, q2, q3)
-#endif
         if (k3 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w3; else tie = true; }
         if (k2 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w2; else tie = true; }
         if (k1 < INF) { if (sp < cap) stack[(sp++) * QA_BLOCK] = w1; else tie = true; }
@@ -988,13 +953,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
       nSlots += (unsigned) nI;
       ++nRounds;
     }
-#if QA_WF_IFIF
-    const bool atLeaf = have && !over && (cur & QA_BVH_LEAF_BIT) && cur != QA_DONE;   // includes lanes that have just reached a leaf
-    const int nL = __popcll(__ballot(atLeaf));
-    if (nL > 0) {
-#else
     else if (nL > 0) {
-#endif
       if (atLeaf) {
         Ray ray;
         ray.p = lo;
@@ -1024,7 +983,6 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
 
   // ---- statistics: one atomic per wave and counter
   unsigned long long v[8] = {nJobsDone, nNode, nLeaf, nTri, nFlag, nSusp, nSlots, nRounds};
-  (void) nTop;
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(b.stats);
   for (int i = 0; i < 8; ++i) {
     unsigned long long x = v[i];

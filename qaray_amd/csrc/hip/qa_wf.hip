@@ -168,37 +168,8 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
   for (const DMesh &dm : c->hostMeshes) if (dm.useWide) wideNeed = std::max(wideNeed, dm.wideStack);
   const uint32_t traceStack = std::min(wideNeed, w.stackCap);
 
-  // top levels of the wide trees in LDS: QA_WF_TOP_KB KB shared evenly by the distinct meshes (at most 8); off by default
-  WfBuf tops;
-  memset(&tops, 0, sizeof(tops));
-  {
-    const qa_flat_header *h = reinterpret_cast<const qa_flat_header *>(c->hostBlob.data());
-    const qa_instance *inst = QA_BLOB_PTR(qa_instance, c->hostBlob.data(), h->off_instances);
-    std::vector<int> meshes;
-    for (uint32_t k = 0; k < h->num_instances && k < 32; ++k)
-      if (inst[k].obj_type == QA_OBJ_MESH && c->hostMeshes[inst[k].mesh].useWide && c->hostMeshes[inst[k].mesh].wnodeCount > 0 &&
-          std::find(meshes.begin(), meshes.end(), inst[k].mesh) == meshes.end() && meshes.size() < 8)
-        meshes.push_back(inst[k].mesh);
-    const uint32_t budgetNodes = w.topKB * 1024u / 64u;
-    const uint32_t share = meshes.empty() ? 0u : budgetNodes / (uint32_t) meshes.size();
-    uint32_t off = 0;
-    for (int mi : meshes) {
-      const DMesh &dm = c->hostMeshes[mi];
-      const uint32_t cnt = std::min(share, dm.wnodeCount);
-      if (!cnt) continue;
-      tops.topSrc[tops.topCopies] = reinterpret_cast<const uint4 *>(dm.wnodes);
-      tops.topOff[tops.topCopies] = off;
-      tops.topCnt[tops.topCopies] = cnt;
-      for (uint32_t k = 0; k < h->num_instances && k < 32; ++k)
-        if (inst[k].obj_type == QA_OBJ_MESH && inst[k].mesh == mi) { tops.instTopOff[k] = off; tops.instTopCnt[k] = cnt; }
-      off += 4 * cnt;
-      tops.topCopies++;
-    }
-    tops.topVec4 = off;
-  }
   const size_t stackLds = (size_t) ds.stackDepth * QA_BLOCK * sizeof(uint32_t);
-  const size_t traceLds = (size_t) traceStack * QA_BLOCK * sizeof(uint32_t) + (size_t) tops.topVec4 * 16;
-  if (traceLds > 64 * 1024) return Fail(QA_EUNSUPPORTED, "staged trace stage: stacks + tree tops exceed 64 KB of LDS (lower QA_WF_TOP_KB)");
+  const size_t traceLds = (size_t) traceStack * QA_BLOCK * sizeof(uint32_t);
   // persistent grids: with several groups every stage kernel takes a slice of the chip (2 workgroups per CU by default),
   // so that kernels of different groups are resident together; a single group takes what fits
   int perCU = w.traceBlocksPerCU;
@@ -240,13 +211,6 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     b.groupCount = (uint32_t) G;
     b.numLights = (uint32_t) w.numLights;
     for (int j = 0; j < QA_WF_MAX_LIGHTS; ++j) b.lightIdx[j] = w.lightIdx[j];
-    memcpy(b.instTopOff, tops.instTopOff, sizeof(b.instTopOff));
-    memcpy(b.instTopCnt, tops.instTopCnt, sizeof(b.instTopCnt));
-    memcpy(b.topSrc, tops.topSrc, sizeof(b.topSrc));
-    memcpy(b.topOff, tops.topOff, sizeof(b.topOff));
-    memcpy(b.topCnt, tops.topCnt, sizeof(b.topCnt));
-    b.topCopies = tops.topCopies;
-    b.topVec4 = tops.topVec4;
     b.refillAt = refillAt;
     b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;
     const size_t rays = slots * (1 + b.numLights);

@@ -68,11 +68,6 @@ struct WfBuf {
   uint32_t contCap;
   uint32_t stackDepth;        // LDS stack entries per lane of wf_redo (reference tree depth)
   uint32_t traceStack;        // ... of wf_trace (4-wide tree; a full stack sends the ray to wf_redo)
-  // top levels of the wide trees staged in wf_trace's LDS (behind the stacks): per instance where its tree's top
-  // sits (16-byte units) and how many nodes, and the list of copies a workgroup makes at kernel start
-  uint32_t instTopOff[32], instTopCnt[32];
-  const uint4 *topSrc[8];
-  uint32_t topOff[8], topCnt[8], topCopies, topVec4;
   uint32_t gateOpen;          // this pass may start new samples (set per pass by the host)
   uint32_t refillAt;          // lanes of a wave that must be out of work before it commits / refills (QA_WF_REFILL)
   uint32_t debug;             // QA_WF_DEBUG bits: 1 = skip the order check
