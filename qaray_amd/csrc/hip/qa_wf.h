@@ -765,7 +765,7 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
 // walking, the finished lanes commit (closest: one 64-bit atomicMin of (distance, instance, triangle); shadow:
 // one atomicAnd), the over-budget lanes write their job back with its stack (it continues in the next pass: a
 // pass never waits for the ray that grazes a gridded wall for thousands of steps), and all of them take new
-// jobs from a range of the queue the wave has reserved with one atomic per 256 jobs.
+// jobs from a range of the queue the wave has reserved with one atomic per 128 jobs (WfBuf::reserve).
 // What makes the answers the reference's: wf_logic's order check of the winning hit (wfHitDetails); here, a tie
 // (a second triangle passing the inside test at exactly the held distance), a full stack, and a shadow hit
 // whose reference leaf fails the strict test against the ray's t_max all send the ray to wf_redo.
@@ -776,7 +776,6 @@ __global__ __launch_bounds__(QA_BLOCK) void wf_cull(const DScene sc, WfBuf b, Wf
 #define QA_WF_TRACE_WAVES 5
 #endif
 #define QA_WF_NOBEST 0xFFFFFFFFu
-#define QA_WF_RESERVE 256u
 
 __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DScene sc, WfBuf b, WfCounters *ctr, uint32_t parity,
                                                                           uint32_t budget)
@@ -814,6 +813,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
   const unsigned lane = __lane_id();
   const unsigned nCont = min(b.contCount[parity], b.contCap), nNew = min(ctr->nJobs, b.jobCap);
   const unsigned total = nCont + nNew;
+  const unsigned reserve = b.reserve;   // jobs a wave reserves with one atomic
   const float INF = __builtin_inff();
 
   bool have = false, over = false, exhausted = false, tie = false;
@@ -880,11 +880,11 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WF_TRACE_WAVES) void wf_trace(const DS
       if (idle) {
         if (rNext >= rEnd && !exhausted) {
           unsigned rb = 0;
-          if (lane == 0) rb = atomicAdd(&ctr->jobHead, QA_WF_RESERVE);
+          if (lane == 0) rb = atomicAdd(&ctr->jobHead, reserve);
           rb = __shfl(rb, 0);
           rNext = rb;
-          rEnd = min(rb + QA_WF_RESERVE, total);
-          if (rb + QA_WF_RESERVE >= total) exhausted = true;
+          rEnd = min(rb + reserve, total);
+          if (rb + reserve >= total) exhausted = true;
           if (rb >= total) { rNext = rEnd = 0; }
         }
         const uint32_t avail = rEnd - rNext;

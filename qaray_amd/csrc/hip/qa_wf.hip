@@ -212,6 +212,7 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     b.numLights = (uint32_t) w.numLights;
     for (int j = 0; j < QA_WF_MAX_LIGHTS; ++j) b.lightIdx[j] = w.lightIdx[j];
     b.refillAt = refillAt;
+    b.reserve = getenv("QA_WF_RESERVE") ? (uint32_t) std::max(64, atoi(getenv("QA_WF_RESERVE"))) : 128u;   // 64 / 128 / 256 @ 64 spp: C3 313 / 324 / 316, C4 1522 / 1473 / 1370, C5 810 / 815 / 791 Msamples/s
     b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;
     const size_t rays = slots * (1 + b.numLights);
     Shape &sh = shape[gi];

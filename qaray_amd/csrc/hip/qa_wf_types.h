@@ -69,6 +69,7 @@ struct WfBuf {
   uint32_t stackDepth;        // LDS stack entries per lane of wf_redo (reference tree depth)
   uint32_t traceStack;        // ... of wf_trace (4-wide tree; a full stack sends the ray to wf_redo)
   uint32_t gateOpen;          // this pass may start new samples (set per pass by the host)
+  uint32_t reserve;           // jobs a wave of wf_trace reserves with one atomic (QA_WF_RESERVE)
   uint32_t refillAt;          // lanes of a wave that must be out of work before it commits / refills (QA_WF_REFILL)
   uint32_t debug;             // QA_WF_DEBUG bits: 1 = skip the order check
   WfStats *stats;
