@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "qa_kernel.h"
+#include "qa_kernel_cs.h"
 #include "qa_ctx.h"
 #include "qa_fastbvh.h"
 #include "qa_widebvh.h"
@@ -64,6 +64,8 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
 static void SetKernelName(qa_ctx *c)
 {
   char name[160];
+  if (c->kernelCs) snprintf(name, sizeof(name), "qa_integrate_cs<TEX=%d>", (int) c->textured);
+  else
   snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured,
            (int) c->area);
   const WfHost &w = c->wf;
@@ -89,6 +91,17 @@ static int SelectKernel(qa_ctx *c)
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
+  // Cooperative shadow walks (qa_kernel_cs.h): lit scenes in global memory without area lights.  QA_COOP=0: off.
+  c->kernelCs = nullptr;
+  {
+    const char *e = getenv("QA_COOP");
+    if (!c->resident && lights && !c->area && c->csFits && c->stackDepth * 64u >= 128u + 512u && !(e && !strcmp(e, "0"))) {
+      c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true> : (KernelFn) qa_integrate_cs<false>;
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytes) != hipSuccess || n < 1) n = 2;
+      c->blocksPerCUCs = n > 8 ? 8 : n;
+    }
+  }
   SetKernelName(c);
   return QA_OK;
 }
@@ -153,6 +166,7 @@ static int PrepareScene(qa_ctx *c)
   std::vector<std::vector<DTri>> allTris(h->num_meshes);
   std::vector<std::vector<DTriShade>> allShade(h->num_meshes);
   std::vector<std::vector<DNode>> allFNodes(h->num_meshes);     // the library's own trees (qa_fastbvh.h)
+  bool csFits = true;   // qa_kernel_cs.h: pool items hold 22 bits of node index / triangle offset
   std::vector<std::vector<DTri>> allFTris(h->num_meshes);
   std::vector<std::vector<uint32_t>> allFMap(h->num_meshes);
   std::vector<WideBvh> allWide(h->num_meshes);                  // 4-wide trees over the triangles (qa_widebvh.h)
@@ -442,6 +456,7 @@ static int PrepareScene(qa_ctx *c)
     dm.wrootWord = allWide[mi].rootWord;
     dm.wideStack = 3 * allWide[mi].depth + 2;
     dm.wnodeCount = (uint32_t) allWide[mi].nodes.size();
+    if (dm.wnodeCount > QA_CS_INDEX_MASK || m.num_faces > QA_CS_INDEX_MASK) csFits = false;
     dm.nearPad = meshSlack[mi].nearPad;
     dm.cancelDist = meshSlack[mi].cancelDist;
     {
@@ -613,6 +628,7 @@ static int PrepareScene(qa_ctx *c)
     ds.rootIdentity = (memcmp(inst[0].tm, I, 36) == 0 && memcmp(inst[0].itm, I, 36) == 0 && memcmp(inst[0].pos, Z, 12) == 0) ? 1 : 0;
   }
   c->haveScene = true;
+  c->csFits = csFits;
   SelectStaged(c);
   return SelectKernel(c);
 }
@@ -707,13 +723,14 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   }
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;
+  const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
   const size_t ldsBytes = pmOn ? c->ldsBytesPm : c->ldsBytes;
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
-                               : ((flags & QA_RENDER_STATS) ? c->kernelStats : c->kernel);
+                               : ((flags & QA_RENDER_STATS) ? c->kernelStats : (cs ? c->kernelCs : c->kernel));
 
   const unsigned tiles = (unsigned) ((x1 - x0 + 7) / 8) * (unsigned) ownRows;
   const long long needBlocks = ((long long) tiles * 64 + QA_BLOCK - 1) / QA_BLOCK;
-  long long blocks = (long long) c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : (pmOn ? c->blocksPerCUPm : c->blocksPerCUAuto));
+  long long blocks = (long long) c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : (pmOn ? c->blocksPerCUPm : (cs ? c->blocksPerCUCs : c->blocksPerCUAuto)));
   if (pmOn && blocks > (long long) c->numCUs * 8) blocks = (long long) c->numCUs * 8;   // the heap scratch is sized for this
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;

@@ -108,6 +108,10 @@ struct qa_ctx {
   // photon / caustics maps (qa_photon.hip); valid until the next scene upload or qa_photon_maps_clear
   bool photonReady = false;
   KernelFn kernelPm = nullptr, kernelPmStats = nullptr;
+  // the megakernel with cooperative shadow walks (qa_kernel_cs.h): lit global-memory scenes without area lights
+  KernelFn kernelCs = nullptr;
+  bool csFits = false;          // every wide tree's node indices and triangle offsets fit the pool's 22-bit item field
+  int blocksPerCUCs = 2;
   int blocksPerCUPm = 2;
   uint32_t stackDepthPm = 0;   // LDS stack entries per lane when the kd-tree gather runs on it
   size_t ldsBytesPm = 0;

@@ -20,7 +20,7 @@ variants = []
 for a in args:
     name, _, envs = a.partition(":")
     variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
-KNOBS = ("QA_HIP_LIB", "QA_PIPELINE", "QA_WIDE", "QA_WF_BUDGET", "QA_WF_BLOCKS", "QA_SYNC", "QA_WF_STACK", "QA_WF_REFILL", "QA_WF_GROUPS", "QA_WF_GATE", "QA_WIDE_LEAF", "QA_WF_REDO_ASYNC", "QA_WF_LOGIC_BLOCKS", "QA_WF_RESERVE")
+KNOBS = ("QA_HIP_LIB", "QA_PIPELINE", "QA_WIDE", "QA_WF_BUDGET", "QA_WF_BLOCKS", "QA_SYNC", "QA_WF_STACK", "QA_WF_REFILL", "QA_WF_GROUPS", "QA_WF_GATE", "QA_WIDE_LEAF", "QA_WF_REDO_ASYNC", "QA_WF_LOGIC_BLOCKS", "QA_WF_RESERVE", "QA_COOP")
 res = {}
 for name, env in variants:
     for k in KNOBS: os.environ.pop(k, None)
