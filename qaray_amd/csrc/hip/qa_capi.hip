@@ -95,7 +95,7 @@ static int SelectKernel(qa_ctx *c)
   c->kernelCs = nullptr;
   {
     const char *e = getenv("QA_COOP");
-    if (!c->resident && lights && !c->area && c->csFits && c->stackDepth * 64u >= 128u + 512u && !(e && !strcmp(e, "0"))) {
+    if (!c->resident && lights && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && !(e && !strcmp(e, "0"))) {
       c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true> : (KernelFn) qa_integrate_cs<false>;
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytes) != hipSuccess || n < 1) n = 2;

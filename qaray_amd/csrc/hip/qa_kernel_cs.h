@@ -164,6 +164,228 @@ __device__ __forceinline__ bool csAnyHitMesh(const DMesh &m, bool go, const Ray 
   return hasHit;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Closest-hit walks by the whole wave.  Same pool; behind it 64 result keys (distance bits << 32 | element: one
+// ds_min_u64 per accepted triangle, and the distance half is what every lane prunes and accepts against, so a hit found by
+// one lane shortens the work of all lanes on that ray at once) and 64 flag words.  A triangle that passes the inside test at
+// exactly the distance held - whether that distance was there before the test or arrived from another lane at the same
+// moment (the atomic's return value) - raises the flag: the one situation in which the ORDER of the tests decides
+// (hitMesh then repeats the query in the reference's order, as after a tie of the sequential 4-wide walk).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long *csKey(uint32_t *pool, uint32_t cap, uint32_t owner)
+{
+  // 64 keys = two pool rows of 64 words; key o sits in row o / 32
+  return reinterpret_cast<unsigned long long *>(&csSlot(pool, cap + (owner >> 5) * 64u)) + (owner & 31u);
+}
+
+__device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ray &r, f3 drcp, float pad, float limit, uint32_t *pool, uint32_t cap,
+                                              float &hz, uint32_t &found, bool &tie)
+{
+  const unsigned lane = __lane_id();
+  const float INF = __builtin_inff();
+  const uint4 *wn = reinterpret_cast<const uint4 *>(m.wnodes), *tris = reinterpret_cast<const uint4 *>(m.wtris);
+  *csKey(pool, cap, lane) = ((unsigned long long) __float_as_uint(limit) << 32) | 0xFFFFFFFFull;
+  csSlot(pool, cap + 128 + lane) = 0;
+  const unsigned long long mk = __ballot(own);
+  uint32_t n = (uint32_t) __popcll(mk);
+  if (own) csSlot(pool, (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))) = m.wrootWord | (lane << QA_CS_OWNER_SHIFT);
+  csWaveSync();
+  while (n) {
+    const uint32_t take = n < 64u ? n : 64u;
+    const bool work = lane < take;
+    const uint32_t item = work ? csSlot(pool, n - take + lane) : 0u;
+    n -= take;
+    const uint32_t owner = (item >> QA_CS_OWNER_SHIFT) & 63u;
+    const f3 op = F3(__shfl(r.p.x, (int) owner), __shfl(r.p.y, (int) owner), __shfl(r.p.z, (int) owner));
+    const f3 od = F3(__shfl(r.d.x, (int) owner), __shfl(r.d.y, (int) owner), __shfl(r.d.z, (int) owner));
+    const f3 orc = F3(__shfl(drcp.x, (int) owner), __shfl(drcp.y, (int) owner), __shfl(drcp.z, (int) owner));
+    const float opad = __shfl(pad, (int) owner);
+    unsigned long long *key = csKey(pool, cap, owner);
+    const bool live = work && csSlot(pool, cap + 128 + owner) == 0;
+    const float hzNow = __uint_as_float((uint32_t) (*key >> 32));   // the distance the owner's ray holds right now
+    const bool isLeaf = (item & QA_BVH_LEAF_BIT) != 0;
+    float k0 = INF, k1 = INF, k2 = INF, k3 = INF;
+    uint32_t w0 = QA_DONE, w1 = QA_DONE, w2 = QA_DONE, w3 = QA_DONE;
+    if (live && !isLeaf) {
+      const uint4 *nd = wn + 4 * (size_t) (item & QA_CS_INDEX_MASK);
+      const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
+      const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
+      const f3 drcp = orc;
+      const float hz = hzNow;   // (the names QA_WIDE_CHILD uses)
+      w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
+      QA_WIDE_CHILD(k0, w0, 0)
+      QA_WIDE_CHILD(k1, w1, 1)
+      QA_WIDE_CHILD(k2, w2, 2)
+      QA_WIDE_CHILD(k3, w3, 3)
+      // farthest first: the pool is popped from its top, so the nearest child of a node is looked at first
+      QA_WIDE_CE(k0, w0, k1, w1)
+      QA_WIDE_CE(k2, w2, k3, w3)
+      QA_WIDE_CE(k0, w0, k2, w2)
+      QA_WIDE_CE(k1, w1, k3, w3)
+      QA_WIDE_CE(k1, w1, k2, w2)
+    }
+#define QA_CS_PUSH(K, W)                                                                                     \
+    {                                                                                                        \
+      const bool p = K < INF;                                                                                \
+      const unsigned long long pm = __ballot(p);                                                             \
+      if (p) {                                                                                               \
+        const uint32_t at = n + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));                           \
+        if (at < cap) csSlot(pool, at) = W | (owner << QA_CS_OWNER_SHIFT);                                   \
+        else atomicOr(&csSlot(pool, cap + 128 + owner), 1u);                                                 \
+      }                                                                                                      \
+      n += (uint32_t) __popcll(pm);                                                                          \
+      n = n < cap ? n : cap;                                                                                 \
+    }
+    QA_CS_PUSH(k3, w3)
+    QA_CS_PUSH(k2, w2)
+    QA_CS_PUSH(k1, w1)
+    QA_CS_PUSH(k0, w0)
+#undef QA_CS_PUSH
+    if (live && isLeaf) {
+      Ray oray;
+      oray.p = op;
+      oray.d = od;
+      const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
+      const uint32_t first = item & QA_CS_INDEX_MASK;
+      float hzl = hzNow;
+      bool tl = false;
+      for (uint32_t i = 0; i < count; ++i) {
+        const uint4 *t = tris + 3 * (size_t) (first + i);
+        const uint4 t2 = ldGlobal(t + 2);
+        if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
+          const unsigned long long mine = ((unsigned long long) __float_as_uint(hzl) << 32) | (unsigned long long) (t2.w >> 2);
+          const unsigned long long old = atomicMin(key, mine);
+          if ((uint32_t) (old >> 32) == __float_as_uint(hzl) && old != mine) tl = true;   // another lane accepted this very distance meanwhile
+        }
+      }
+      if (tl) atomicOr(&csSlot(pool, cap + 128 + owner), 1u);
+    }
+    csWaveSync();
+  }
+  const unsigned long long k = *csKey(pool, cap, lane);
+  found = own ? (uint32_t) k : ~0u;            // 0xFFFFFFFF: nothing accepted
+  hz = __uint_as_float((uint32_t) (k >> 32));
+  tie = own && csSlot(pool, cap + 128 + lane) != 0;
+  csWaveSync();
+}
+
+// hitMesh<RES = false>(closest = true) of qa_kernel.h with the 4-wide walk done by the whole wave; `go`: this lane has a ray.
+__device__ __forceinline__ bool csHitMeshClosest(const DMesh &m, bool go, const Ray &ray, Hit &h, int k, uint32_t *pool, uint32_t cap,
+                                                 uint32_t *stack, DCounters &cnt, TriPick &pick)
+{
+  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  const bool nearZero = qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f;
+  if (go) {
+    float entry, meshExit;
+    if (nearZero) boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+    else boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+    if (entry > h.z || entry > meshExit) go = false;
+  }
+  if (m.num_faces == 0) go = false;
+  const uint4 *nodes = reinterpret_cast<const uint4 *>(m.nodes), *tris = reinterpret_cast<const uint4 *>(m.tris), *shade = reinterpret_cast<const uint4 *>(m.shade);
+  const float hz0 = h.z;
+  const bool coop = go && m.useWide && insideCancelReach(m, ray.p);
+  bool redo = go && !coop, hasHit = false;
+  uint32_t bestTri = 0;
+  if (__any(coop)) {
+    const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
+    const float pad = m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
+    float hz;
+    uint32_t found;
+    bool tie;
+    csWalkClosest(m, coop, ray, drcp, pad, hz0, pool, cap, hz, found, tie);
+    if (coop) {
+      redo = tie;
+      if (found != 0xFFFFFFFFu && !tie) {
+        const uint32_t leaf = ldGlobal(shade + 3 * (size_t) found + 2).w;   // DTriShade::pad
+        if (refReaches<true>(nodes, leaf, ray, drcp, !nearZero, hz)) {
+          hasHit = true;
+          bestTri = found;
+          h.z = hz;
+        } else redo = true;
+      }
+    }
+  }
+  if (redo) {
+    h.z = hz0;
+    bool tie = false;
+    const bool fastSlab = !__any(nearZero);
+    hasHit = walkBVH<false, false, true>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, true, stack, cnt, bestTri, tie);
+  }
+  if (hasHit) {
+    float ba = 0, bb = 0;
+    {
+      const uint4 *t = tris + 3 * (size_t) bestTri;
+      triangleDetails(ldGlobal(t), ldGlobal(t + 1), ldGlobal(t + 2), ray, h, ba, bb);
+    }
+    // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
+    const uint4 *s = shade + 3 * (size_t) bestTri;
+    const uint4 s0 = ldGlobal(s), s1 = ldGlobal(s + 1), s2 = ldGlobal(s + 2);
+    const float bc = 1.f - ba - bb;
+    const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)), n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));
+    h.N = (n0 * ba + n1 * bb) + n2 * bc;
+    h.mtlID = (int) s2.y;
+    h.node = k;
+    pick.tri = bestTri;
+    pick.a = ba;
+    pick.b = bb;
+  }
+  return hasHit;
+}
+
+// Scene::TraceNodeNormal (traceClosest of qa_kernel.h) for the lanes with `act`; every lane of the wave calls this.
+template <bool TEX>
+__device__ __forceinline__ bool csTraceClosest(const DScene &sc, bool act, const Ray &world, const RayDiff &wd, Hit &h, TexHit &th, uint32_t *pool,
+                                               uint32_t cap, uint32_t *stack, DCounters &cnt)
+{
+  if (!__any(act)) return false;
+  if (act) cnt.casts_normal++;
+  const Ray r0 = rootRay<false>(sc, world);
+  GroupRay grp;
+  grp.node = -1;
+  grp.ray = r0;
+  bool any = false;
+  for (int k = 1; k < sc.num_inst; ++k) {
+    const qa_instance in = instAt<false>(sc, k);
+    const int type = in.obj_type;
+    if (type == QA_OBJ_NONE) continue;
+    Ray r;
+    RayDiff rd;
+    if (TEX) localRayDiff<false>(sc, k, world, wd, r, rd);
+    else r = localRayInGroup<false>(sc, k, r0, grp);
+    bool hit = false;
+    if (type == QA_OBJ_SPHERE) {
+      if (act) hit = hitSphere(r, h, k, true);
+      if (TEX && hit) texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+    } else if (type == QA_OBJ_PLANE) {
+      if (act) hit = hitPlane(r, h, k, true);
+      if (TEX && hit) texPlane(r.p, rd.dx, rd.dy, h.p, th);
+    } else {
+      const DMesh m = meshAt<false>(sc, in.mesh);
+      TriPick pick;
+      hit = csHitMeshClosest(m, act, r, h, k, pool, cap, stack, cnt, pick);
+      if (TEX && hit && m.hasVT) {
+        const uint4 *t = reinterpret_cast<const uint4 *>(m.tris) + 3 * (size_t) pick.tri;
+        texTriangle(ldGlobal(t), ldGlobal(t + 1), ldGlobal(t + 2), m.vt + 6 * (size_t) pick.tri, r.p, rd.dx, rd.dy, pick.a, pick.b, th);
+      }
+    }
+    any |= hit;
+  }
+  if (any) {
+    // Node::FromNodeCoords at every level from the hit node up to and including the root (src/core/node.cpp:127-139)
+    for (int a = h.node; a >= 0; a = instAt<false>(sc, a).parent) {
+      if (a == 0 && sc.rootIdentity) {
+        h.N = normalize(h.N);
+        break;
+      }
+      const qa_instance ia = instAt<false>(sc, a);
+      h.p = mulMV(ia.tm, h.p) + ld3(ia.pos);
+      h.N = normalize(mulTMV(ia.itm, h.N));
+    }
+  }
+  return any;
+}
+
 // The shadow ray illuminate() (qa_kernel.h) shoots from p towards light l
 __device__ __forceinline__ void csShadowRay(const qa_light &l, f3 p, Ray &w, float &tmax)
 {
@@ -263,7 +485,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
   const uint4 *mtlTable = reinterpret_cast<const uint4 *>(sc.mtl);
   // the wave's pool for cooperative walks: its own columns of the per-lane stacks
   uint32_t *pool = reinterpret_cast<uint32_t *>(s_dyn) + (threadIdx.x / 64) * 64;
-  const uint32_t poolCap = sc.stackDepth * 64u - 128u;
+  const uint32_t poolCap = sc.stackDepth * 64u - 192u;   // behind the pool: result words / keys and flags (csWalkAny, csWalkClosest)
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
@@ -374,8 +596,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
     th.uvw = F3(0.5f, 0.5f, 0.5f);
     th.duvw0 = th.duvw1 = F3(0, 0, 0);
     th.hasTexture = false;
-    bool found = false;
-    if (act) found = traceClosest<false, TEX, false>(mem, sc, path.ray, pathDiff, h, th, stack, cnt);
+    const bool found = csTraceClosest<TEX>(sc, act, path.ray, pathDiff, h, th, pool, poolCap, stack, cnt);
 
     // ---- D. shade up to the lights (qa_integrate, section D)
     bool lit = false;
