@@ -64,7 +64,7 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
 static void SetKernelName(qa_ctx *c)
 {
   char name[160];
-  if (c->kernelCs) snprintf(name, sizeof(name), "qa_integrate_cs<TEX=%d>", (int) c->textured);
+  if (c->kernelCs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d>", (int) (c->ds.num_lights > 0), (int) c->textured);
   else
   snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured,
            (int) c->area);
@@ -91,12 +91,13 @@ static int SelectKernel(qa_ctx *c)
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *) c->kernel, QA_BLOCK, c->ldsBytes) != hipSuccess || resident < 1)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
-  // Cooperative shadow walks (qa_kernel_cs.h): lit scenes in global memory without area lights.  QA_COOP=0: off.
+  // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
   c->kernelCs = nullptr;
   {
     const char *e = getenv("QA_COOP");
-    if (!c->resident && lights && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && !(e && !strcmp(e, "0"))) {
-      c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true> : (KernelFn) qa_integrate_cs<false>;
+    if (!c->resident && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && !(e && !strcmp(e, "0"))) {
+      c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true> : (KernelFn) qa_integrate_cs<true, false>)
+                           : (c->textured ? (KernelFn) qa_integrate_cs<false, true> : (KernelFn) qa_integrate_cs<false, false>);
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytes) != hipSuccess || n < 1) n = 2;
       c->blocksPerCUCs = n > 8 ? 8 : n;

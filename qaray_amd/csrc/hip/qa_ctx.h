@@ -108,7 +108,7 @@ struct qa_ctx {
   // photon / caustics maps (qa_photon.hip); valid until the next scene upload or qa_photon_maps_clear
   bool photonReady = false;
   KernelFn kernelPm = nullptr, kernelPmStats = nullptr;
-  // the megakernel with cooperative shadow walks (qa_kernel_cs.h): lit global-memory scenes without area lights
+  // the megakernel with cooperative mesh walks (qa_kernel_cs.h): global-memory scenes without area lights
   KernelFn kernelCs = nullptr;
   bool csFits = false;          // every wide tree's node indices and triangle offsets fit the pool's 22-bit item field
   int blocksPerCUCs = 2;

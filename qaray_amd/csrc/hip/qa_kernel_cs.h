@@ -1,4 +1,4 @@
-// qa_kernel_cs.h — the megakernel for lit scenes whose meshes live in global memory, with COOPERATIVE shadow walks.
+// qa_kernel_cs.h — the megakernel for scenes whose meshes live in global memory, with COOPERATIVE mesh walks.
 //
 // Why.  Shadow queries are half of such a frame (cycle stamps, profiles/round02/megakernel_section_stamps.txt: 55 % of a
 // wave's time on project7_object, 33 % on the tower scene, are the mesh walks of shadow rays), and qa_integrate walks them
@@ -471,10 +471,10 @@ __device__ __forceinline__ f3 csDirectLight(const DScene &sc, f3 p, f3 N, f3 V, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The kernel: qa_integrate<RES = false, LIGHTS = true, TEX, AREA = false> with section D cut where the wave meets for its
+// The kernel: qa_integrate<RES = false, LIGHTS, TEX, AREA = false> with section D cut where the wave meets for its
 // shadow walks.  Dynamic LDS as qa_integrate's: [traversal stacks | sample accumulators].
 // ---------------------------------------------------------------------------------------------
-template <bool TEX>
+template <bool LIGHTS, bool TEX>
 __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -647,9 +647,11 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
       }
     }
     // ---- direct lighting: the whole wave walks the shadow rays of its lit lanes
-    if (__any(lit)) {
-      const uint32_t occl = csShadows(sc, lit, p, pool, poolCap, stack, cnt);
-      if (lit) path.L = path.L + path.T * csDirectLight(sc, p, N, V, sf.kd, sf.ks, sf.gloss, occl);
+    if (LIGHTS) {
+      if (__any(lit)) {
+        const uint32_t occl = csShadows(sc, lit, p, pool, poolCap, stack, cnt);
+        if (lit) path.L = path.L + path.T * csDirectLight(sc, p, N, V, sf.kd, sf.ks, sf.gloss, occl);
+      }
     }
     if (lit) {
       if (sf.spawn) {

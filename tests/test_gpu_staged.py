@@ -206,6 +206,47 @@ def test_big_fuzz_meshes_all_searches_agree(ctx, tmp_path, kind, seed):
     assert rmse(np.nan_to_num(outs["stats"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
 
 
+@pytest.mark.parametrize("case", ["tower", "object", "sheets"])
+def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
+    """qa_integrate_cs (the whole wave walks the closest-hit and shadow queries of a mesh from a pool in LDS, qa_kernel_cs.h)
+    against qa_integrate (every lane walks its own ray; QA_COOP=0 at upload) and the counting kernel (reference tree, walked
+    as the reference walks it): same bits, same cast counts.  The coincident sheets make equal-distance accepts from
+    different lanes in one round - the case the 64-bit key's return value has to catch."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    if case == "sheets":
+        xml = _write_big_fuzz_scene(str(tmp_path), np.random.default_rng(11), "sheets")
+        size, spp = (256, 192), 4
+        blob = load_scene_blob(xml, size=size, asset_root=str(tmp_path))
+    else:
+        size, spp = (480, 270), 8
+        blob = load_scene_blob("trc_scene_tower.xml" if case == "tower" else "example_project7_object.xml", size=size)
+    w, h = size
+    outs, cnts, names = {}, {}, {}
+    old = os.environ.get("QA_COOP")
+    try:
+        for mode in ("coop", "own", "stats"):
+            if mode == "own": os.environ["QA_COOP"] = "0"
+            else: os.environ.pop("QA_COOP", None)
+            c = hip.Context(0)
+            c.upload_scene(blob)
+            c.set_pipeline("mega")
+            c.reset_counters()
+            outs[mode] = c.render_region((0, 0, w, h), spp, stats=(mode == "stats"))
+            cnts[mode] = c.counters()
+            names[mode] = c.kernel_name()
+            c.close()
+    finally:
+        if old is None: os.environ.pop("QA_COOP", None)
+        else: os.environ["QA_COOP"] = old
+    assert "qa_integrate_cs" in names["coop"] and "qa_integrate_cs" not in names["own"], names
+    for mode in ("coop", "own"):
+        for a, b in zip(outs[mode], outs["stats"]):
+            assert np.array_equal(bits(a), bits(b)), mode
+        assert all(cnts[mode][k] == cnts["stats"][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), mode
+
+
 def test_exact_repeat_is_exercised_and_invisible(ctx, tmp_path):
     """Coincident sheets: the staged integrator must send rays to wf_redo (ties / failed order checks) - and the frame
     must not show it."""
