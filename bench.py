@@ -248,6 +248,9 @@ def main():
         elif "RES=1" in kernel_name:
             limiter = ("latency of the LDS-resident tree walk (53 % of wave time on the Cornell box at 5 waves/SIMD; all correctly rounded div / sqrt "
                        "removed: +5.5 % only); not HBM bandwidth (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
+        elif "qa_integrate_cs" in kernel_name:
+            limiter = ("mesh walks of the whole wave from a pool of (ray, node) items in LDS (latency of dependent node reads, ds_bpermute ray "
+                       "fetches) and the scene-graph loop; not HBM bandwidth, not arithmetic (DESIGN.md 4d, profiles/round02/session3_experiments.txt)")
         else:
             limiter = ("mesh walks in global memory at low lane occupancy and the dependent loads of the scene-graph loop; not HBM bandwidth, not "
                        "arithmetic (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
