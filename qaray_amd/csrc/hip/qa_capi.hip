@@ -1080,6 +1080,9 @@ int qa_get_counters(qa_ctx *c, qa_counters *out)
     fprintf(stderr, "[stamps] waves %llu, iterations/wave %.0f, cycles/wave %.3e | share of wave time: fetch+start %.3f, closest %.3f (mesh walks %.3f), shade %.3f, "
             "direct light %.3f (shadow mesh walks %.3f), sample end %.3f, miss branch %.3f, hit before shading %.3f, spawn %.3f\n", h.stamp[9], h.stamp[8] / w, k / w, h.stamp[1] / k, h.stamp[2] / k, h.stamp[3] / k,
             h.stamp[4] / k, h.stamp[5] / k, h.stamp[6] / k, h.stamp[7] / k, h.stamp[10] / k, h.stamp[11] / k, h.stamp[12] / k);
+    if (c->kernelCs && h.stamp[11])   // qa_integrate_cs reuses slots 10 / 11: items taken from the pool / rounds of the cooperative walks
+      fprintf(stderr, "[stamps] cooperative walks: %llu rounds, %.1f of 64 lanes hold an item on average (lane occupancy of the walks %.3f); %.3f of the rounds hold <= 16 items\n", h.stamp[11],
+              (double) h.stamp[10] / (double) h.stamp[11], (double) h.stamp[10] / (64.0 * (double) h.stamp[11]), (double) h.stamp[12] / (double) h.stamp[11]);
   }
 #endif
   return QA_OK;

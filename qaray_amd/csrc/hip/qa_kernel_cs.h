@@ -23,6 +23,11 @@
 
 namespace qa {
 
+#ifdef QA_STAMPS
+#define QA_FILL(cnt) (cnt).sl
+#else
+#define QA_FILL(cnt) nullptr
+#endif
 #define QA_CS_OWNER_SHIFT 22            /* pool item = child word | owner lane << 22 (inner: node index, leaf: flag, count, offset) */
 #define QA_CS_INDEX_MASK 0x3FFFFFu      /* node indices / triangle offsets of a mesh must fit 22 bits (host check) */
 
@@ -40,7 +45,7 @@ __device__ __forceinline__ uint32_t &csSlot(uint32_t *pool, uint32_t i) { return
 // Any-hit walk of mesh m's 4-wide tree for the lanes with `own` (node-local ray r, padded by `pad`, limit tmax), by the
 // whole wave.  found = an accepted element of the lane's own ray (or ~0u); tie = the query has to be repeated exactly.
 __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r, f3 drcp, float pad, float tmax, uint32_t *pool, uint32_t cap,
-                                          uint32_t &found, bool &tie)
+                                          uint32_t &found, bool &tie, unsigned long long *fill = nullptr)
 {
   const unsigned lane = __lane_id();
   const float INF = __builtin_inff();
@@ -52,9 +57,16 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
   if (own) csSlot(pool, (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))) = m.wrootWord | (lane << QA_CS_OWNER_SHIFT);
   csWaveSync();
   while (n) {
-    const uint32_t take = n < 64u ? n : 64u;
-    const bool work = lane < take;
-    const uint32_t item = work ? csSlot(pool, n - take + lane) : 0u;
+    // With at most 16 items in the pool four lanes share an item: each tests ONE child of the node (or one triangle of the
+    // leaf), so an underfilled round costs a quarter of the arithmetic - and all items are taken every round.
+    const bool quad = n <= 16u;
+    const uint32_t take = quad ? n : (n < 64u ? n : 64u);
+    const uint32_t idx = quad ? (lane >> 2) : lane, sub = lane & 3u;
+#ifdef QA_STAMPS
+    if (fill && lane == 0) { fill[10] += quad ? 4u * take : take; fill[11] += 1; fill[12] += (take <= 16u) ? 1 : 0; }   /* lanes at work / rounds / rounds with <= 16 items */
+#endif
+    const bool work = idx < take;
+    const uint32_t item = work ? csSlot(pool, n - take + idx) : 0u;
     n -= take;
     const uint32_t owner = (item >> QA_CS_OWNER_SHIFT) & 63u;
     // the owner's ray, out of its registers
@@ -71,11 +83,16 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
       const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
       const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
       const f3 drcp = orc;   // (the name QA_WIDE_CHILD uses)
-      w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
-      QA_WIDE_CHILD(k0, w0, 0)
-      QA_WIDE_CHILD(k1, w1, 1)
-      QA_WIDE_CHILD(k2, w2, 2)
-      QA_WIDE_CHILD(k3, w3, 3)
+      if (quad) {
+        w0 = sub == 0 ? q3.x : sub == 1 ? q3.y : sub == 2 ? q3.z : q3.w;
+        QA_WIDE_CHILD(k0, w0, sub)
+      } else {
+        w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
+        QA_WIDE_CHILD(k0, w0, 0)
+        QA_WIDE_CHILD(k1, w1, 1)
+        QA_WIDE_CHILD(k2, w2, 2)
+        QA_WIDE_CHILD(k3, w3, 3)
+      }
     }
     // children the ray enters go back into the pool (any order will do for an any-hit query)
 #define QA_CS_PUSH(K, W)                                                                                     \
@@ -91,9 +108,11 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
       n = n < cap ? n : cap;                                                                                 \
     }
     QA_CS_PUSH(k0, w0)
-    QA_CS_PUSH(k1, w1)
-    QA_CS_PUSH(k2, w2)
-    QA_CS_PUSH(k3, w3)
+    if (!quad) {
+      QA_CS_PUSH(k1, w1)
+      QA_CS_PUSH(k2, w2)
+      QA_CS_PUSH(k3, w3)
+    }
 #undef QA_CS_PUSH
     if (live && isLeaf) {
       Ray oray;
@@ -101,9 +120,10 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
       oray.d = od;
       const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
       const uint32_t first = item & QA_CS_INDEX_MASK;
+      const uint32_t i0 = quad ? sub : 0u, i1 = quad ? (sub < count ? sub + 1u : sub) : count;   // quad: this lane's one triangle
       float hzl = hz;
       bool tl = false, stop = false;
-      for (uint32_t i = 0; i < count && !stop; ++i) {
+      for (uint32_t i = i0; i < i1 && !stop; ++i) {
         const uint4 *t = tris + 3 * (size_t) (first + i);
         const uint4 t2 = ldGlobal(t + 2);
         if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
@@ -141,7 +161,9 @@ __device__ __forceinline__ bool csAnyHitMesh(const DMesh &m, bool go, const Ray 
     const float pad = m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
     uint32_t found;
     bool tie;
-    csWalkAny(m, coop, ray, drcp, pad, tmax, pool, cap, found, tie);
+    QA_T(tW)
+    csWalkAny(m, coop, ray, drcp, pad, tmax, pool, cap, found, tie, QA_FILL(cnt));
+    QA_TACC(cnt.sl[6], tW)
     if (coop) {
       redo = tie;
       if (found != ~0u && !tie) {
@@ -179,7 +201,7 @@ __device__ __forceinline__ unsigned long long *csKey(uint32_t *pool, uint32_t ca
 }
 
 __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ray &r, f3 drcp, float pad, float limit, uint32_t *pool, uint32_t cap,
-                                              float &hz, uint32_t &found, bool &tie)
+                                              float &hz, uint32_t &found, bool &tie, unsigned long long *fill = nullptr)
 {
   const unsigned lane = __lane_id();
   const float INF = __builtin_inff();
@@ -191,9 +213,14 @@ __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ra
   if (own) csSlot(pool, (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))) = m.wrootWord | (lane << QA_CS_OWNER_SHIFT);
   csWaveSync();
   while (n) {
-    const uint32_t take = n < 64u ? n : 64u;
-    const bool work = lane < take;
-    const uint32_t item = work ? csSlot(pool, n - take + lane) : 0u;
+    const bool quad = n <= 16u;   // four lanes per item, one child / triangle each (csWalkAny)
+    const uint32_t take = quad ? n : (n < 64u ? n : 64u);
+    const uint32_t idx = quad ? (lane >> 2) : lane, sub = lane & 3u;
+#ifdef QA_STAMPS
+    if (fill && lane == 0) { fill[10] += quad ? 4u * take : take; fill[11] += 1; fill[12] += (take <= 16u) ? 1 : 0; }
+#endif
+    const bool work = idx < take;
+    const uint32_t item = work ? csSlot(pool, n - take + idx) : 0u;
     n -= take;
     const uint32_t owner = (item >> QA_CS_OWNER_SHIFT) & 63u;
     const f3 op = F3(__shfl(r.p.x, (int) owner), __shfl(r.p.y, (int) owner), __shfl(r.p.z, (int) owner));
@@ -212,17 +239,22 @@ __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ra
       const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
       const f3 drcp = orc;
       const float hz = hzNow;   // (the names QA_WIDE_CHILD uses)
-      w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
-      QA_WIDE_CHILD(k0, w0, 0)
-      QA_WIDE_CHILD(k1, w1, 1)
-      QA_WIDE_CHILD(k2, w2, 2)
-      QA_WIDE_CHILD(k3, w3, 3)
-      // farthest first: the pool is popped from its top, so the nearest child of a node is looked at first
-      QA_WIDE_CE(k0, w0, k1, w1)
-      QA_WIDE_CE(k2, w2, k3, w3)
-      QA_WIDE_CE(k0, w0, k2, w2)
-      QA_WIDE_CE(k1, w1, k3, w3)
-      QA_WIDE_CE(k1, w1, k2, w2)
+      if (quad) {
+        w3 = sub == 0 ? q3.x : sub == 1 ? q3.y : sub == 2 ? q3.z : q3.w;   // (every item is taken every round while quad: no order to keep)
+        QA_WIDE_CHILD(k3, w3, sub)
+      } else {
+        w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
+        QA_WIDE_CHILD(k0, w0, 0)
+        QA_WIDE_CHILD(k1, w1, 1)
+        QA_WIDE_CHILD(k2, w2, 2)
+        QA_WIDE_CHILD(k3, w3, 3)
+        // farthest first: the pool is popped from its top, so the nearest child of a node is looked at first
+        QA_WIDE_CE(k0, w0, k1, w1)
+        QA_WIDE_CE(k2, w2, k3, w3)
+        QA_WIDE_CE(k0, w0, k2, w2)
+        QA_WIDE_CE(k1, w1, k3, w3)
+        QA_WIDE_CE(k1, w1, k2, w2)
+      }
     }
 #define QA_CS_PUSH(K, W)                                                                                     \
     {                                                                                                        \
@@ -237,9 +269,11 @@ __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ra
       n = n < cap ? n : cap;                                                                                 \
     }
     QA_CS_PUSH(k3, w3)
-    QA_CS_PUSH(k2, w2)
-    QA_CS_PUSH(k1, w1)
-    QA_CS_PUSH(k0, w0)
+    if (!quad) {
+      QA_CS_PUSH(k2, w2)
+      QA_CS_PUSH(k1, w1)
+      QA_CS_PUSH(k0, w0)
+    }
 #undef QA_CS_PUSH
     if (live && isLeaf) {
       Ray oray;
@@ -247,9 +281,10 @@ __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ra
       oray.d = od;
       const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
       const uint32_t first = item & QA_CS_INDEX_MASK;
+      const uint32_t i0 = quad ? sub : 0u, i1 = quad ? (sub < count ? sub + 1u : sub) : count;
       float hzl = hzNow;
       bool tl = false;
-      for (uint32_t i = 0; i < count; ++i) {
+      for (uint32_t i = i0; i < i1; ++i) {
         const uint4 *t = tris + 3 * (size_t) (first + i);
         const uint4 t2 = ldGlobal(t + 2);
         if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
@@ -293,7 +328,9 @@ __device__ __forceinline__ bool csHitMeshClosest(const DMesh &m, bool go, const 
     float hz;
     uint32_t found;
     bool tie;
-    csWalkClosest(m, coop, ray, drcp, pad, hz0, pool, cap, hz, found, tie);
+    QA_T(tW)
+    csWalkClosest(m, coop, ray, drcp, pad, hz0, pool, cap, hz, found, tie, QA_FILL(cnt));
+    QA_TACC(cnt.sl[3], tW)
     if (coop) {
       redo = tie;
       if (found != 0xFFFFFFFFu && !tie) {
@@ -493,6 +530,12 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
   const unsigned lane = __lane_id();
 
   DCounters cnt = {};
+#ifdef QA_STAMPS
+  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][13];
+  cnt.sl = s_stamps[threadIdx.x / 64];
+  if (__lane_id() < 13) cnt.sl[__lane_id()] = 0;
+#endif
+  QA_T(tKernel)
   TexTables tt;
   tt.blob = sc.blob;
   tt.texmap = sc.texmap;
@@ -518,6 +561,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
   bool alive = true, needPixel = true, needSample = false;
 
   for (;;) {
+    QA_T(tA)
     // ---- A. tile fetch (qa_integrate, section A)
     const unsigned long long aliveMask = __ballot(alive);
     const unsigned long long want = __ballot(alive && needPixel);
@@ -582,6 +626,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
       needSample = false;
       cnt.samples++;
     }
+    QA_TACC(cnt.sl[1], tA)
     // ---- C. trace (qa_integrate, section C)
     const bool act = alive && !needPixel && !needSample;
     bool done = false;
@@ -596,7 +641,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
     th.uvw = F3(0.5f, 0.5f, 0.5f);
     th.duvw0 = th.duvw1 = F3(0, 0, 0);
     th.hasTexture = false;
+    QA_T(tC)
     const bool found = csTraceClosest<TEX>(sc, act, path.ray, pathDiff, h, th, pool, poolCap, stack, cnt);
+    QA_TACC(cnt.sl[2], tC)
+    QA_T(tD)
 
     // ---- D. shade up to the lights (qa_integrate, section D)
     bool lit = false;
@@ -646,13 +694,17 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
         }
       }
     }
+    QA_TACC(cnt.sl[4], tD)
     // ---- direct lighting: the whole wave walks the shadow rays of its lit lanes
     if (LIGHTS) {
       if (__any(lit)) {
+        QA_T(tL)
         const uint32_t occl = csShadows(sc, lit, p, pool, poolCap, stack, cnt);
         if (lit) path.L = path.L + path.T * csDirectLight(sc, p, N, V, sf.kd, sf.ks, sf.gloss, occl);
+        QA_TACC(cnt.sl[5], tL)
       }
     }
+    QA_T(tE)
     if (lit) {
       if (sf.spawn) {
         path.ray.p = p;
@@ -691,6 +743,10 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
         needPixel = true;
       }
     }
+    QA_TACC(cnt.sl[7], tE)
+#ifdef QA_STAMPS
+    if (lane == 0) cnt.sl[8] += 1;
+#endif
   }
 
   unsigned long long v[6] = {cnt.samples, cnt.casts_normal, cnt.casts_shadow, cnt.bvh_nodes, cnt.tri_tests, cnt.pixels};
@@ -700,6 +756,13 @@ __global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const 
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
     if (lane == 0 && x) atomicAdd(&dst[i], x);
   }
+#ifdef QA_STAMPS
+  if (lane == 0) {
+    cnt.sl[0] = __builtin_readcyclecounter() - tKernel;
+    cnt.sl[9] = 1;
+    for (int i = 0; i < 13; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
+  }
+#endif
 }
 
 }  // namespace qa
