@@ -70,7 +70,7 @@ static void SetKernelName(qa_ctx *c)
            (int) c->area);
   const WfHost &w = c->wf;
   const char *staged = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
-  if (!w.eligible || w.mode == 0) c->kernelName = name;
+  if (!w.eligible || w.mode == 0 || (w.mode == 2 && c->kernelCs)) c->kernelName = name;   // auto keeps the cooperative megakernel (Render)
   else if (w.mode == 1) c->kernelName = staged;
   else if (w.decision < 0) c->kernelName = std::string(name) + " (staged integrator eligible: decided by a timed probe at the first large frame)";
   else {
@@ -744,7 +744,11 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     WfHost &w = c->wf;
     if (w.probing) staged = w.probeWhich == 1;
     else if (w.mode == 1) staged = true;
-    else if (w.mode == 2) {
+    else if (w.mode == 2 && c->kernelCs) {
+      // with cooperative mesh walks (qa_kernel_cs.h) the megakernel is the faster integrator on every scene measured
+      // (BASELINE C3 / C4 / C5: 712 / 4587 / 1190 against 345 / 1642 / 886 Msamples/s): no probe, staged only on request
+      staged = false;
+    } else if (w.mode == 2) {
       const size_t pixels = (size_t) tiles * 64;
       if (w.decision < 0 && spp_min == spp_max && spp_max >= 128 && pixels >= 500000 && !pmOn) {
         // Both integrators render 32 spp of this very region, each with its own start-up and drain; the faster one takes

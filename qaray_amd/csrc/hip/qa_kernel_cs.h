@@ -511,8 +511,16 @@ __device__ __forceinline__ f3 csDirectLight(const DScene &sc, f3 p, f3 N, f3 V, 
 // The kernel: qa_integrate<RES = false, LIGHTS, TEX, AREA = false> with section D cut where the wave meets for its
 // shadow walks.  Dynamic LDS as qa_integrate's: [traversal stacks | sample accumulators].
 // ---------------------------------------------------------------------------------------------
+// Waves per SIMD the register allocator must leave room for: three for the untextured variants (the walks' bookkeeping
+// and the owner rays spill at four: C5 1262 -> 1439, C4 4007 -> 4622 Msamples/s), four for the textured ones (C3 731 vs 711).
+#ifndef QA_CS_WAVES_NOTEX
+#define QA_CS_WAVES_NOTEX 3
+#endif
+#ifndef QA_CS_WAVES_TEX
+#define QA_CS_WAVES_TEX 4
+#endif
 template <bool LIGHTS, bool TEX>
-__global__ __launch_bounds__(QA_BLOCK, QA_MIN_WAVES) void qa_integrate_cs(const DScene sc, const RenderParams rp)
+__global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
   SceneMem<false> mem;

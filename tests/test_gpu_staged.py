@@ -316,26 +316,45 @@ def test_staged_tile_groups_on_streams_equal_the_megakernel(ctx, scene):
         assert c == cref
 
 
-def test_auto_probe_picks_an_integrator_and_keeps_the_bits(ctx):
-    """QA_PIPE_AUTO: the first large frame (>= 128 spp, >= 0.5 Mpixel) is preceded by timed 32-spp renders by both
+def test_auto_probe_picks_an_integrator_and_keeps_the_bits():
+    """QA_PIPE_AUTO.  With cooperative walks (the default) the megakernel is kept without a probe.  Without them
+    (QA_COOP=0 at upload) the first large frame (>= 128 spp, >= 0.5 Mpixel) is preceded by timed 32-spp renders by both
     integrators; whatever it picks, the frame equals the megakernel's, and the probe leaves the counters alone."""
+    from qaray_amd import hip
     from qaray_amd.host import load_scene_blob
     ensure_assets()
     W, H, spp = 1280, 720, 128
-    ctx.upload_scene(load_scene_blob("trc_scene_tower.xml", size=(W, H)))
-    ctx.set_pipeline("auto")
-    assert "probe" in ctx.kernel_name() and "decided" in ctx.kernel_name()
-    ctx.reset_counters()
-    a = ctx.render_region((0, 0, W, H), spp)
-    ca = ctx.counters()
-    assert "probe at 32 spp: megakernel" in ctx.kernel_name()
-    assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
-    ctx.set_pipeline("mega")
-    ctx.reset_counters()
-    b = ctx.render_region((0, 0, W, H), spp)
-    cb = ctx.counters()
-    for x, y in zip(a, b):
-        assert np.array_equal(bits(x), bits(y))
+    blob = load_scene_blob("trc_scene_tower.xml", size=(W, H))
+    old = os.environ.get("QA_COOP")
+    try:
+        os.environ.pop("QA_COOP", None)
+        c = hip.Context(0)
+        c.upload_scene(blob)
+        c.set_pipeline("auto")
+        assert "qa_integrate_cs" in c.kernel_name() and "probe" not in c.kernel_name(), c.kernel_name()
+        ref = c.render_region((0, 0, W, H), spp)
+        assert "qa_integrate_cs" in c.kernel_name() and "probe" not in c.kernel_name(), c.kernel_name()
+        c.close()
+        os.environ["QA_COOP"] = "0"
+        c = hip.Context(0)
+        c.upload_scene(blob)
+        c.set_pipeline("auto")
+        assert "probe" in c.kernel_name() and "decided" in c.kernel_name()
+        c.reset_counters()
+        a = c.render_region((0, 0, W, H), spp)
+        ca = c.counters()
+        assert "probe at 32 spp: megakernel" in c.kernel_name()
+        assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
+        c.set_pipeline("mega")
+        c.reset_counters()
+        b = c.render_region((0, 0, W, H), spp)
+        cb = c.counters()
+        c.close()
+    finally:
+        if old is None: os.environ.pop("QA_COOP", None)
+        else: os.environ["QA_COOP"] = old
+    for x, y, z in zip(a, b, ref):
+        assert np.array_equal(bits(x), bits(y)) and np.array_equal(bits(x), bits(z))
     assert ca == cb
 
 
