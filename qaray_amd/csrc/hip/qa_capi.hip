@@ -725,6 +725,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
+  ds.csPoolLimit = getenv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(getenv("QA_CS_POOL"))) : 0u;
   const size_t ldsBytes = pmOn ? c->ldsBytesPm : c->ldsBytes;
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
                                : ((flags & QA_RENDER_STATS) ? c->kernelStats : (cs ? c->kernelCs : c->kernel));

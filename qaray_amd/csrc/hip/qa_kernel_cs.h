@@ -530,7 +530,9 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   const uint4 *mtlTable = reinterpret_cast<const uint4 *>(sc.mtl);
   // the wave's pool for cooperative walks: its own columns of the per-lane stacks
   uint32_t *pool = reinterpret_cast<uint32_t *>(s_dyn) + (threadIdx.x / 64) * 64;
-  const uint32_t poolCap = sc.stackDepth * 64u - 192u;   // behind the pool: result words / keys and flags (csWalkAny, csWalkClosest)
+  // behind the pool: result words / keys and flags (csWalkAny, csWalkClosest).  (A limit below the LDS there is: tests of the overflow path.)
+  const uint32_t poolRoom = sc.stackDepth * 64u - 192u;
+  const uint32_t poolCap = (sc.csPoolLimit && sc.csPoolLimit < poolRoom) ? (sc.csPoolLimit & ~63u) : poolRoom;
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;

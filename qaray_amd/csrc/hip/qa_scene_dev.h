@@ -158,7 +158,7 @@ struct DScene {
   uint32_t rootIdentity;       // instance 0 has tm = itm = I and pos = 0 (always, for XML scenes)
   uint32_t stackDepth;         // entries per lane of the LDS traversal stack
   int32_t bgTexmap, envTexmap; // texmaps of the background / environment colours (-1 = none)
-  uint32_t pad;
+  uint32_t csPoolLimit;        // qa_integrate_cs: upper bound for the pool capacity (0 = none; QA_CS_POOL, tests: forces the overflow path)
   // resident scenes only: the tables themselves, in the kernel-argument segment
   qa_instance instv[QA_KARG_INST];
   DMesh meshv[QA_KARG_MESH];

@@ -226,9 +226,12 @@ def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
     outs, cnts, names = {}, {}, {}
     old = os.environ.get("QA_COOP")
     try:
-        for mode in ("coop", "own", "stats"):
+        for mode in ("coop", "tiny", "own", "stats"):
             if mode == "own": os.environ["QA_COOP"] = "0"
             else: os.environ.pop("QA_COOP", None)
+            # "tiny": a pool of 64 items overflows constantly - those rays must come back from the exact repeat unchanged
+            if mode == "tiny": os.environ["QA_CS_POOL"] = "64"
+            else: os.environ.pop("QA_CS_POOL", None)
             c = hip.Context(0)
             c.upload_scene(blob)
             c.set_pipeline("mega")
@@ -238,10 +241,11 @@ def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
             names[mode] = c.kernel_name()
             c.close()
     finally:
+        os.environ.pop("QA_CS_POOL", None)
         if old is None: os.environ.pop("QA_COOP", None)
         else: os.environ["QA_COOP"] = old
-    assert "qa_integrate_cs" in names["coop"] and "qa_integrate_cs" not in names["own"], names
-    for mode in ("coop", "own"):
+    assert "qa_integrate_cs" in names["coop"] and "qa_integrate_cs" in names["tiny"] and "qa_integrate_cs" not in names["own"], names
+    for mode in ("coop", "tiny", "own"):
         for a, b in zip(outs[mode], outs["stats"]):
             assert np.array_equal(bits(a), bits(b)), mode
         assert all(cnts[mode][k] == cnts["stats"][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), mode
