@@ -136,10 +136,12 @@ const char *qa_get_kernel_name(qa_ctx *ctx);
 int qa_get_staged_stats(qa_ctx *ctx, uint64_t out[QA_STAGED_STATS]);
 
 /* Scenes whose geometry does not fit LDS can run on two integrators that return the same bits: the persistent
- * megakernel and the staged pipeline (logic / cull / trace / redo stages exchanging rays through queues in HBM).
- * QA_PIPE_AUTO (default; env QA_PIPELINE=mega|staged|auto sets the initial mode) times both on a short (4 - 16 spp) frame of
- * the region the first time a frame of >= 64 spp and >= 0.5 Mpixel is asked for and keeps the faster one until the
- * next scene upload; smaller frames run on the megakernel.  Scenes the staged pipeline cannot take (LDS-resident
+ * megakernel (for scenes without area lights with cooperative mesh walks: the whole wave walks a mesh's queries from a pool
+ * of (ray, node) items in LDS, qa_kernel_cs.h) and the staged pipeline (logic / cull / trace / redo stages exchanging rays
+ * through queues in HBM).  QA_PIPE_AUTO (default; env QA_PIPELINE=mega|staged|auto sets the initial mode) keeps the megakernel
+ * wherever it has cooperative walks (the faster integrator on every scene measured); elsewhere it renders 32 spp of the
+ * region with both the first time a frame of >= 128 spp and >= 0.5 Mpixel is asked for and keeps the faster one until the
+ * next scene upload, smaller frames run on the megakernel.  Scenes the staged pipeline cannot take (LDS-resident
  * scenes, area lights, photon maps, QA_RENDER_STATS frames, > 4 non-ambient lights, > 31 nodes) always run on the
  * megakernel, whatever the mode. */
 #define QA_PIPE_MEGA 0
