@@ -120,10 +120,10 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
       oray.d = od;
       const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
       const uint32_t first = item & QA_CS_INDEX_MASK;
-      const uint32_t i0 = quad ? sub : 0u, i1 = quad ? (sub < count ? sub + 1u : sub) : count;   // quad: this lane's one triangle
+      const uint32_t i0 = quad ? sub : 0u, di = quad ? 4u : 1u;   // quad: this lane's triangle(s) sub, sub + 4, ...
       float hzl = hz;
       bool tl = false, stop = false;
-      for (uint32_t i = i0; i < i1 && !stop; ++i) {
+      for (uint32_t i = i0; i < count && !stop; i += di) {
         const uint4 *t = tris + 3 * (size_t) (first + i);
         const uint4 t2 = ldGlobal(t + 2);
         if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
@@ -281,10 +281,10 @@ __device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ra
       oray.d = od;
       const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
       const uint32_t first = item & QA_CS_INDEX_MASK;
-      const uint32_t i0 = quad ? sub : 0u, i1 = quad ? (sub < count ? sub + 1u : sub) : count;
+      const uint32_t i0 = quad ? sub : 0u, di = quad ? 4u : 1u;
       float hzl = hzNow;
       bool tl = false;
-      for (uint32_t i = i0; i < i1; ++i) {
+      for (uint32_t i = i0; i < count; i += di) {
         const uint4 *t = tris + 3 * (size_t) (first + i);
         const uint4 t2 = ldGlobal(t + 2);
         if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
