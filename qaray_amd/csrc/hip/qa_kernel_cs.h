@@ -386,22 +386,34 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, bool act, const
     const qa_instance in = instAt<false>(sc, k);
     const int type = in.obj_type;
     if (type == QA_OBJ_NONE) continue;
-    Ray r;
-    RayDiff rd;
-    if (TEX) localRayDiff<false>(sc, k, world, wd, r, rd);
-    else r = localRayInGroup<false>(sc, k, r0, grp);
+    // (the node-local differential directions are only needed by an object that is hit: they are built then, by the
+    // same chain of operations localRayDiff performs for the central ray, instead of for every node of every query)
+    const Ray r = localRayInGroup<false>(sc, k, r0, grp);
     bool hit = false;
     if (type == QA_OBJ_SPHERE) {
       if (act) hit = hitSphere(r, h, k, true);
-      if (TEX && hit) texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+      if (TEX && hit) {
+        Ray r2;
+        RayDiff rd;
+        localRayDiff<false>(sc, k, world, wd, r2, rd);
+        texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+      }
     } else if (type == QA_OBJ_PLANE) {
       if (act) hit = hitPlane(r, h, k, true);
-      if (TEX && hit) texPlane(r.p, rd.dx, rd.dy, h.p, th);
+      if (TEX && hit) {
+        Ray r2;
+        RayDiff rd;
+        localRayDiff<false>(sc, k, world, wd, r2, rd);
+        texPlane(r.p, rd.dx, rd.dy, h.p, th);
+      }
     } else {
       const DMesh m = meshAt<false>(sc, in.mesh);
       TriPick pick;
       hit = csHitMeshClosest(m, act, r, h, k, pool, cap, stack, cnt, pick);
       if (TEX && hit && m.hasVT) {
+        Ray r2;
+        RayDiff rd;
+        localRayDiff<false>(sc, k, world, wd, r2, rd);
         const uint4 *t = reinterpret_cast<const uint4 *>(m.tris) + 3 * (size_t) pick.tri;
         texTriangle(ldGlobal(t), ldGlobal(t + 1), ldGlobal(t + 2), m.vt + 6 * (size_t) pick.tri, r.p, rd.dx, rd.dy, pick.a, pick.b, th);
       }
