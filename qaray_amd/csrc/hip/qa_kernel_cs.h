@@ -94,7 +94,8 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
         QA_WIDE_CHILD(k3, w3, 3)
       }
     }
-    // children the ray enters go back into the pool (any order will do for an any-hit query)
+    // children the ray enters go back into the pool (any order will do for an any-hit query; looking at the nearest child
+    // first was measured: C3 749 -> 699, C5 1436 -> 1413 Msamples/s - the sort costs more than it finds)
 #define QA_CS_PUSH(K, W)                                                                                     \
     {                                                                                                        \
       const bool p = K < INF;                                                                                \
