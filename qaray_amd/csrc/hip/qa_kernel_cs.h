@@ -523,6 +523,9 @@ __device__ __forceinline__ f3 csDirectLight(const DScene &sc, f3 p, f3 N, f3 V, 
 // ---------------------------------------------------------------------------------------------
 // The kernel: qa_integrate<RES = false, LIGHTS, TEX, AREA = false> with section D cut where the wave meets for its
 // shadow walks.  Dynamic LDS as qa_integrate's: [traversal stacks | sample accumulators].
+// Sections A, B and E are qa_integrate's text, repeated here on purpose: moving them into functions shared by both kernels
+// changes the register allocation of qa_integrate's LDS-resident variants - the Cornell-box kernel lost 8 % (13.0 -> 12.0
+// Gsamples/s) with only the tile fetch factored out (profiles/round02/session3_experiments.txt, item 14).
 // ---------------------------------------------------------------------------------------------
 // Waves per SIMD the register allocator must leave room for: three for the untextured variants (the walks' bookkeeping
 // and the owner rays spill at four: C5 1262 -> 1439, C4 4007 -> 4622 Msamples/s), four for the textured ones (C3 731 vs 711).
