@@ -188,7 +188,8 @@ __device__ __forceinline__ bool csAnyHitMesh(const DMesh &m, bool go, const Ray 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Closest-hit walks by the whole wave.  Same pool; behind it 64 result keys (distance bits << 32 | element: one
+// Closest-hit walks by the whole wave.  (A twin of csWalkAny on purpose: folded into one template the textured kernel runs
+// 4 % slower - C3 748 -> 719 Msamples/s - for the same instructions in another order; session3_experiments.txt, item 18.)  Same pool; behind it 64 result keys (distance bits << 32 | element: one
 // ds_min_u64 per accepted triangle, and the distance half is what every lane prunes and accepts against, so a hit found by
 // one lane shortens the work of all lanes on that ray at once) and 64 flag words.  A triangle that passes the inside test at
 // exactly the distance held - whether that distance was there before the test or arrived from another lane at the same
