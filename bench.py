@@ -28,7 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch / HIP initialise: see qaray_amd/hip.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # this process only, before torch / HIP initialise: --pipeline staged runs four tile groups on streams
 
 import numpy as np  # noqa: E402
 
@@ -156,6 +156,8 @@ def main():
 
     ctx = hip.Context(local_rank)
     ctx.set_pipeline(args.pipeline)
+    if args.pipeline == "staged":
+        ctx.set_option("staged_groups", 4)   # with GPU_MAX_HW_QUEUES=8 (set above, before HIP initialises)
     # rank 0 parses + flattens; everyone receives the blob over RCCL and adopts it from HBM
     blob = load_scene_blob(scene_xml, size=(W, H)) if rank == 0 else None
     if world > 1:

@@ -124,8 +124,10 @@ int qa_get_kernel_time(qa_ctx *ctx, double *total_ms, uint64_t *launches);
 int qa_reset_kernel_time(qa_ctx *ctx);
 
 /* Which integrator the uploaded scene runs on, e.g. "qa_integrate<RES=1,LIGHTS=0,TEX=0,AREA=0>" (one persistent
- * megakernel, LDS-resident scene) or "staged: wf_logic + wf_cull + wf_trace + wf_redo" (scenes whose
- * geometry does not fit LDS).  The pointer stays valid until the next scene upload. */
+ * megakernel, LDS-resident scene), "qa_integrate_cs<LIGHTS=1,TEX=1>" (megakernel with cooperative mesh walks) or
+ * "staged: wf_logic + wf_cull + wf_trace + wf_redo (n tile groups)".  Before the first frame after an upload (or after
+ * qa_set_pipeline / qa_set_option) this is the plan; afterwards it names what the LAST qa_render_* call launched,
+ * including "+ photon-map gathers" / "counting variant" for those frames.  Valid until the next call on the context. */
 const char *qa_get_kernel_name(qa_ctx *ctx);
 /* Diagnostics of the staged integrator since the last qa_reset_counters (synchronises):
  * [0] passes, [1] closest-hit rays, [2] shadow rays, [3] BVH jobs queued, [4] rays repeated exactly,
@@ -136,18 +138,28 @@ const char *qa_get_kernel_name(qa_ctx *ctx);
 int qa_get_staged_stats(qa_ctx *ctx, uint64_t out[QA_STAGED_STATS]);
 
 /* Scenes whose geometry does not fit LDS can run on two integrators that return the same bits: the persistent
- * megakernel (for scenes without area lights with cooperative mesh walks: the whole wave walks a mesh's queries from a pool
+ * megakernel (for scenes without area lights with cooperative mesh walks: the whole wave walks its mesh queries from a pool
  * of (ray, node) items in LDS, qa_kernel_cs.h) and the staged pipeline (logic / cull / trace / redo stages exchanging rays
- * through queues in HBM).  QA_PIPE_AUTO (default; env QA_PIPELINE=mega|staged|auto sets the initial mode) keeps the megakernel
- * wherever it has cooperative walks (the faster integrator on every scene measured); elsewhere it renders 32 spp of the
- * region with both the first time a frame of >= 128 spp and >= 0.5 Mpixel is asked for and keeps the faster one until the
- * next scene upload, smaller frames run on the megakernel.  Scenes the staged pipeline cannot take (LDS-resident
- * scenes, area lights, photon maps, QA_RENDER_STATS frames, > 4 non-ambient lights, > 31 nodes) always run on the
- * megakernel, whatever the mode. */
+ * through queues in HBM, qa_wf.h).  QA_PIPE_AUTO (the default) and QA_PIPE_MEGA run the megakernel - the faster integrator
+ * on every scene measured; QA_PIPE_STAGED runs the staged pipeline, which is kept as an independent bitwise cross-check.
+ * Scenes the staged pipeline cannot take (LDS-resident scenes, area lights, photon maps, QA_RENDER_STATS frames, > 4
+ * non-ambient lights, > 31 nodes) always run on the megakernel, whatever the mode. */
 #define QA_PIPE_MEGA 0
 #define QA_PIPE_STAGED 1
 #define QA_PIPE_AUTO 2
 int qa_set_pipeline(qa_ctx *ctx, int mode);
+
+/* Options an embedding application or a test may set (the product library reads no environment variable of its own;
+ * the developer knobs of the A/B scripts exist only in builds made with -DQA_DEV_KNOBS):
+ *   "coop"           1 (default) / 0: cooperative mesh walks where the scene allows them; 0 = every lane walks its own ray
+ *   "cs_pool_limit"  n > 0: upper bound for the pool of the cooperative walks (tests: forces the overflow path); 0 = none
+ *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together
+ *   "tile_order"     1 (default) / 0: tiles handed out centre-first
+ *   "staged_groups"  1 (default) .. 8 tile groups of the staged pipeline, each on its own stream; more than one only pays
+ *                    when the process started the HIP runtime with GPU_MAX_HW_QUEUES >= 8
+ *   "verbose"        1: tree statistics and launch shapes on stderr at upload
+ * Unknown names return QA_EINVAL. */
+int qa_set_option(qa_ctx *ctx, const char *name, long long value);
 
 /* Launch geometry (0 = library default). blocks_per_cu * CUs persistent workgroups of `threads`. */
 int qa_set_launch_config(qa_ctx *ctx, int blocks_per_cu, int threads_per_block);

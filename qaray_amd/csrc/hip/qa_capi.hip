@@ -61,23 +61,35 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
   return stats ? PickShading<false, true>(lights, tex, area) : PickShading<false, false>(lights, tex, area);
 }
 
-static void SetKernelName(qa_ctx *c)
+static int NonAmbientLights(const qa_ctx *c)
+{
+  if (c->hostBlob.size() < sizeof(qa_flat_header)) return 0;
+  const qa_flat_header *h = reinterpret_cast<const qa_flat_header *>(c->hostBlob.data());
+  const qa_light *light = QA_BLOB_PTR(qa_light, c->hostBlob.data(), h->off_lights);
+  int n = 0;
+  for (uint32_t i = 0; i < h->num_lights; ++i) n += light[i].type != QA_LIGHT_AMBIENT;
+  return n;
+}
+
+static const char *kStagedName = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
+static std::string MegaName(const qa_ctx *c, bool cs)
 {
   char name[160];
-  if (c->kernelCs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d>", (int) (c->ds.num_lights > 0), (int) c->textured);
-  else
-  snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured,
-           (int) c->area);
+  if (cs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d>", (int) (c->ds.num_lights > 0), (int) c->textured);
+  else snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->area);
+  return name;
+}
+// The integrator the next plain frame is planned to run on.  What a frame really ran on (photon-map variants, counting
+// kernels, frames the staged integrator refused) is recorded at launch: qa_get_kernel_name returns that once a frame has run.
+static void SetKernelName(qa_ctx *c)
+{
   const WfHost &w = c->wf;
-  const char *staged = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
-  if (!w.eligible || w.mode == 0 || (w.mode == 2 && c->kernelCs)) c->kernelName = name;   // auto keeps the cooperative megakernel (Render)
-  else if (w.mode == 1) c->kernelName = staged;
-  else if (w.decision < 0) c->kernelName = std::string(name) + " (staged integrator eligible: decided by a timed probe at the first large frame)";
-  else {
-    char buf[96];
-    snprintf(buf, sizeof(buf), " (probe at %d spp: megakernel %.1f ms, staged %.1f ms)", w.probeSpp, w.probeMs[0], w.probeMs[1]);
-    c->kernelName = std::string(w.decision == 1 ? staged : name) + buf;
-  }
+  if (w.eligible && w.mode == QA_PIPE_STAGED) {
+    char buf[64];
+    snprintf(buf, sizeof(buf), " (%d tile group%s)", w.numGroups, w.numGroups == 1 ? "" : "s");
+    c->kernelName = std::string(kStagedName) + buf;
+  } else c->kernelName = MegaName(c, c->kernelCs != nullptr);
+  c->launchedName.clear();
 }
 
 // Choose the kernel variant for the uploaded scene and size the persistent grid to what is
@@ -92,10 +104,11 @@ static int SelectKernel(qa_ctx *c)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
   // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
+  // csShadows keeps one occlusion bit per non-ambient light in a 32-bit mask: scenes with more lights keep qa_integrate.
   c->kernelCs = nullptr;
   {
-    const char *e = getenv("QA_COOP");
-    if (!c->resident && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && !(e && !strcmp(e, "0"))) {
+    const char *e = DevEnv("QA_COOP");
+    if (!c->resident && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && c->optCoop && NonAmbientLights(c) <= 32 && !(e && !strcmp(e, "0"))) {
       c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true> : (KernelFn) qa_integrate_cs<true, false>)
                            : (c->textured ? (KernelFn) qa_integrate_cs<false, true> : (KernelFn) qa_integrate_cs<false, false>);
       int n = 0;
@@ -104,6 +117,9 @@ static int SelectKernel(qa_ctx *c)
     }
   }
   SetKernelName(c);
+  if (c->optVerbose || DevEnv("QA_FAST_VERBOSE"))
+    fprintf(stderr, "kernel %s: dynamic LDS %zu B per workgroup (stack depth %u), workgroups per CU: megakernel %d, cooperative %d\n", c->kernelName.c_str(),
+            c->ldsBytes, c->stackDepth, c->blocksPerCUAuto, c->kernelCs ? c->blocksPerCUCs : 0);
   return QA_OK;
 }
 
@@ -336,7 +352,7 @@ static int PrepareScene(qa_ctx *c)
         allFNodes[mi] = fb.nodes;
         fastCost[mi] = {0.0, 0.0};
         // global-memory scene: the 4-wide tree over the reference leaves, and the inside test's fp32 slack
-        if (m.num_faces > 0 && m.num_bvh_nodes > 1 && !(getenv("QA_WIDE") && atoi(getenv("QA_WIDE")) == 0)) {
+        if (m.num_faces > 0 && m.num_bvh_nodes > 1 && !(DevEnv("QA_WIDE") && atoi(DevEnv("QA_WIDE")) == 0)) {
           try {
             std::vector<float> ev(9 * (size_t) m.num_faces), tb(6 * (size_t) m.num_faces);
             std::vector<unsigned char> skip(m.num_faces, 0);
@@ -352,7 +368,7 @@ static int PrepareScene(qa_ctx *c)
             }
             // triangles per leaf: 3 (same-box A/B of 1 / 2 / 3 / 4 / 6 / 8: C3 288 / 363 / 373 / 382 / 389 / 371, C5 391 / 612 / 614 / 594 /
             // 565 / 539 Msamples/s on the megakernel; the staged integrator is flat between 2 and 4)
-            const unsigned wideLeaf = getenv("QA_WIDE_LEAF") ? (unsigned) atoi(getenv("QA_WIDE_LEAF")) : 3u;
+            const unsigned wideLeaf = DevEnv("QA_WIDE_LEAF") ? (unsigned) atoi(DevEnv("QA_WIDE_LEAF")) : 3u;
             WideBvhBuilder(tb.data(), skip.data(), m.num_faces, wideLeaf).Run(allWide[mi]);
             // the triangle records once more in the wide tree's leaf order; the element id rides above the 2-bit axis
             allWTris[mi].resize(allWide[mi].order.size());
@@ -365,13 +381,13 @@ static int PrepareScene(qa_ctx *c)
           const uint32_t need = 3 * allWide[mi].depth + 2;
           if (need > stackNeed) stackNeed = need;
           if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
-          if (getenv("QA_FAST_VERBOSE"))
+          if ((c->optVerbose || DevEnv("QA_FAST_VERBOSE")))
             fprintf(stderr, "mesh %u: %u triangles, reference tree %u nodes depth %u; wide tree %zu nodes depth %u; inside-test slack %g, cancel distance %g, |coord| <= %g\n",
                     mi, m.num_faces, m.num_bvh_nodes, stackNeed, allWide[mi].nodes.size(), allWide[mi].depth, (double) meshSlack[mi].nearPad,
                     (double) meshSlack[mi].cancelDist, (double) absMax);
         }
       } else {
-      const unsigned leafMax = getenv("QA_FAST_LEAF") ? (unsigned) atoi(getenv("QA_FAST_LEAF")) : 2u;
+      const unsigned leafMax = DevEnv("QA_FAST_LEAF") ? (unsigned) atoi(DevEnv("QA_FAST_LEAF")) : 2u;
       try { FastBvhBuilder(bounds.data(), m.num_faces, leafMax).Run(fb); } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
       if (fb.nodes.size() & 1) fb.nodes.push_back(DNode{});
       {
@@ -381,7 +397,7 @@ static int PrepareScene(qa_ctx *c)
         const double costRef = m.num_bvh_nodes > 1 ? TreeCost(dn.data(), nodes[1].data, rootBox) : 0;
         const double costFast = TreeCost(fb.nodes.data(), fb.rootData, rootBox);
         fastCost[mi] = {costRef, costFast};
-        if (getenv("QA_FAST_VERBOSE"))
+        if ((c->optVerbose || DevEnv("QA_FAST_VERBOSE")))
           fprintf(stderr, "mesh %u: %u triangles, expected ray cost reference tree %.2f, own tree %.2f (depth %u), smallest altitude %g, |coord| <= %g, %zu distinct normals\n",
                   mi, m.num_faces, costRef, costFast, fb.depth, hMin, (double) absMax, meshNormals[mi].size() / 4);
       }
@@ -433,7 +449,7 @@ static int PrepareScene(qa_ctx *c)
     dm.num_nodes = m.num_bvh_nodes;
     dm.rootData = m.num_bvh_nodes > 1 ? nodes[1].data : QA_DONE;
     dm.frootData = (m.num_faces && allFNodes[mi].size() > 1) ? allFNodes[mi][1].data : QA_DONE;
-    dm.useFast = (totalFaces <= 512 && m.num_bvh_nodes < 0x8000u && m.num_faces <= (getenv("QA_FAST_MAXFACES") ? (uint32_t) atoi(getenv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
+    dm.useFast = (totalFaces <= 512 && m.num_bvh_nodes < 0x8000u && m.num_faces <= (DevEnv("QA_FAST_MAXFACES") ? (uint32_t) atoi(DevEnv("QA_FAST_MAXFACES")) : 0xFFFFFFFFu)) ? 1u : 0u;
     dm.invH = meshInvH[mi];
     dm.absMax = meshAbsMax[mi];
     {
@@ -705,7 +721,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     if (c->tileOrder) rp.tile_order = c->dOrder;
   }
   rp.stop_flag = c->dStopAlias;
-  rp.counters = c->wf.probing ? c->dCountersProbe : c->dCounters;
+  rp.counters = c->dCounters;
   // Scene::usePhotonMap: once qa_photon_maps_build has run, frames gather from the maps
   const bool pmOn = c->photonReady;
   memset(rp.pm, 0, sizeof(rp.pm));
@@ -725,7 +741,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
-  ds.csPoolLimit = getenv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(getenv("QA_CS_POOL"))) : 0u;
+  ds.csPoolLimit = DevEnv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(DevEnv("QA_CS_POOL"))) : c->optCsPool;
   const size_t ldsBytes = pmOn ? c->ldsBytesPm : c->ldsBytes;
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
                                : ((flags & QA_RENDER_STATS) ? c->kernelStats : (cs ? c->kernelCs : c->kernel));
@@ -737,58 +753,10 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
-  // ---- which integrator: the two return the same bits, so the choice is about speed only.  "auto" times both on a
-  // sample of this very region the first time a large frame is asked for (staged wins where BVH walks dominate, the
-  // megakernel where shading does) and keeps the answer until the next scene upload.
-  bool staged = false;
-  if (StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64)) {
-    WfHost &w = c->wf;
-    if (w.probing) staged = w.probeWhich == 1;
-    else if (w.mode == 1) staged = true;
-    else if (w.mode == 2 && c->kernelCs) {
-      // with cooperative mesh walks (qa_kernel_cs.h) the megakernel is the faster integrator on every scene measured
-      // (BASELINE C3 / C4 / C5: 712 / 4587 / 1190 against 345 / 1642 / 886 Msamples/s): no probe, staged only on request
-      staged = false;
-    } else if (w.mode == 2) {
-      const size_t pixels = (size_t) tiles * 64;
-      if (w.decision < 0 && spp_min == spp_max && spp_max >= 128 && pixels >= 500000 && !pmOn) {
-        // Both integrators render 32 spp of this very region, each with its own start-up and drain; the faster one takes
-        // the frame.  Cost: 64 spp-equivalents, once per scene upload (frames below 128 spp are not worth it and take the
-        // megakernel).  Cheaper probes mispredicted: 4 - 16 spp frames extrapolated to the frame's spp miss that staged
-        // passes get slower once the pixels' paths drift apart, and on a sample of the strips both integrators run at
-        // half their full-frame rate (too few pixels in flight for the staged one, a tail of expensive tiles for the
-        // megakernel).
-        const int m = 1;
-        const int ps = 32;
-        hipEvent_t e[3];
-        for (auto &x : e) HIP_TRY(hipEventCreate(&x));
-        float ms[2] = {0, 0};
-        w.probing = true;
-        for (int which = 0; which < 2 && rc == QA_OK; ++which) {   // 0: megakernel, 1: staged
-          w.probeWhich = which;
-          HIP_TRY(hipEventRecord(e[which], s));
-          rc = Render(c, x0, y0, x1, y1, tile_row0, tile_row_step * (which == 0 ? m : 1), ps, ps, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
-        }
-        w.probing = false;
-        if (rc != QA_OK) return rc;
-        HIP_TRY(hipEventRecord(e[2], s));
-        HIP_TRY(hipEventSynchronize(e[2]));
-        HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
-        HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
-        for (auto &x : e) (void) hipEventDestroy(x);
-        ms[0] *= (float) m;
-        w.decision = ms[1] < ms[0] ? 1 : 0;
-        w.probeMs[0] = ms[0];
-        w.probeMs[1] = ms[1];
-        w.probeSpp = ps;
-        w.probeStep = m;
-        SetKernelName(c);
-        // (the tile-order table was rebuilt for the probe's partition and is rebuilt for the frame's by the call below)
-        return Render(c, x0, y0, x1, y1, tile_row0, tile_row_step, spp_min, spp_max, max_bounce, seed, flags, d_rgb, d_depth, d_ns, s);
-      }
-      staged = w.decision == 1;
-    }
-  }
+  // ---- which integrator: both return the same bits.  The staged one (qa_wf.h) runs on request only (QA_PIPE_STAGED): since
+  // the cooperative walks the megakernel is the faster one on every scene measured, and round 2's timed probe between the
+  // two is gone.
+  const bool staged = c->wf.mode == QA_PIPE_STAGED && StagedTakes(c, flags, spp_max, max_bounce, (size_t) tiles * 64);
 
   EventPair ev;
   if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
@@ -803,7 +771,15 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(ev.b, s));
-  if (c->wf.probing) { c->freeEvents.push_back(ev); return QA_OK; }   // not part of the frame's kernel time
+  {
+    // the kernel this frame really ran on
+    if (staged) c->launchedName = c->kernelName;
+    else {
+      c->launchedName = MegaName(c, cs);
+      if (pmOn) c->launchedName += " + photon-map gathers (PHOTON=1)";
+      if (flags & QA_RENDER_STATS) c->launchedName += " counting variant (STATS=1, reference tree)";
+    }
+  }
   c->pending.push_back(ev);
   c->launches++;
   // a caller that never asks for timers or counters must not grow the event list without bound
@@ -914,22 +890,21 @@ int qa_ctx_create(int device_id, qa_ctx **out)
       (e = hipMalloc((void **) &c->dWork, qa_ctx::kCounterRing * sizeof(unsigned int))) != hipSuccess ||
       (e = hipMalloc((void **) &c->dCounters, sizeof(DCounters))) != hipSuccess ||
       (e = hipMemset(c->dCounters, 0, sizeof(DCounters))) != hipSuccess ||
-      (e = hipMalloc((void **) &c->dCountersProbe, sizeof(DCounters))) != hipSuccess ||
       (e = hipHostMalloc((void **) &c->hStop, sizeof(int), hipHostMallocMapped)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("context setup: ") + hipGetErrorString(e));
   }
   *c->hStop = 0;
-  if (const char *e = getenv("QA_SYNC")) c->syncSamples = atoi(e);
-  c->tileOrder = getenv("QA_NO_TILE_ORDER") == nullptr;
-  if (const char *e = getenv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
-  if (const char *e = getenv("QA_WF_GATE")) c->wf.gate = (uint32_t) std::max(1, atoi(e));
-  // several tile groups only pay when their streams get hardware queues of their own (4 per process by default)
-  c->wf.numGroups = (getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8) ? 4 : 1;
-  if (const char *e = getenv("QA_WF_REDO_ASYNC")) c->wf.redoAsync = atoi(e) != 0;
-  if (const char *e = getenv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
-  if (const char *e = getenv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
-  if (const char *e = getenv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
+  if (const char *e = DevEnv("QA_SYNC")) c->syncSamples = atoi(e);
+  c->tileOrder = DevEnv("QA_NO_TILE_ORDER") == nullptr;
+  if (const char *e = DevEnv("QA_WF_BUDGET")) c->wf.budget = atoi(e) > 0 ? (uint32_t) atoi(e) : 512u;
+  if (const char *e = DevEnv("QA_WF_GATE")) c->wf.gate = (uint32_t) std::max(1, atoi(e));
+  // (tile groups of the staged integrator: one unless qa_set_option("staged_groups") says otherwise - several groups only pay
+  // when the process gave the HIP runtime a hardware queue per group stream, GPU_MAX_HW_QUEUES >= 8 before its first call)
+  if (const char *e = DevEnv("QA_WF_REDO_ASYNC")) c->wf.redoAsync = atoi(e) != 0;
+  if (const char *e = DevEnv("QA_WF_GROUPS")) c->wf.numGroups = std::max(1, std::min(atoi(e), (int) WfHost::kMaxGroups));
+  if (const char *e = DevEnv("QA_WF_STACK")) c->wf.stackCap = atoi(e) > 1 ? (uint32_t) atoi(e) : 24u;
+  if (const char *e = DevEnv("QA_WF_BLOCKS")) c->wf.traceBlocksPerCU = atoi(e);
   if ((e = hipHostGetDevicePointer((void **) &c->dStopAlias, c->hStop, 0)) != hipSuccess) {
     qa_ctx_destroy(c);
     return Fail(QA_EHIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
@@ -951,7 +926,6 @@ int qa_ctx_destroy(qa_ctx *c)
   if (c->dOrder) (void) hipFree(c->dOrder);
   if (c->dWork) (void) hipFree(c->dWork);
   if (c->dCounters) (void) hipFree(c->dCounters);
-  if (c->dCountersProbe) (void) hipFree(c->dCountersProbe);
   if (c->hStop) (void) hipHostFree(c->hStop);
   if (c->dRgb) (void) hipFree(c->dRgb);
   if (c->dDepth) (void) hipFree(c->dDepth);
@@ -1123,7 +1097,6 @@ int qa_set_pipeline(qa_ctx *c, int mode)
   if (mode < QA_PIPE_MEGA || mode > QA_PIPE_AUTO) return Fail(QA_EINVAL, "pipeline mode must be QA_PIPE_MEGA, QA_PIPE_STAGED or QA_PIPE_AUTO");
   c->wf.mode = mode;
   c->wf.modeSet = true;
-  c->wf.decision = -1;
   if (c->haveScene) SetKernelName(c);
   return QA_OK;
 }
@@ -1131,7 +1104,7 @@ int qa_set_pipeline(qa_ctx *c, int mode)
 const char *qa_get_kernel_name(qa_ctx *c)
 {
   if (!c || !c->haveScene) return "";
-  return c->kernelName.c_str();
+  return c->launchedName.empty() ? c->kernelName.c_str() : c->launchedName.c_str();
 }
 
 int qa_get_kernel_time(qa_ctx *c, double *total_ms, uint64_t *launches)
@@ -1152,6 +1125,24 @@ int qa_reset_kernel_time(qa_ctx *c)
   if (rc != QA_OK) return rc;
   c->totalMs = 0;
   c->launches = 0;
+  return QA_OK;
+}
+
+int qa_set_option(qa_ctx *c, const char *name, long long value)
+{
+  if (!c || !name) return Fail(QA_EINVAL, "null argument");
+  const std::string n(name);
+  if (n == "coop") {
+    c->optCoop = value != 0;
+    if (c->haveScene) return SelectKernel(c);
+  } else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
+  else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value ? 1 : 0);
+  else if (n == "tile_order") c->tileOrder = value != 0;
+  else if (n == "staged_groups") {
+    c->wf.numGroups = (int) std::max<long long>(1, std::min<long long>(value, WfHost::kMaxGroups));
+    if (c->haveScene) SetKernelName(c);
+  } else if (n == "verbose") c->optVerbose = value != 0;
+  else return Fail(QA_EINVAL, "unknown option '" + n + "'");
   return QA_OK;
 }
 

@@ -23,15 +23,26 @@ inline int Fail(int code, const std::string &msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return Fail(QA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Developer knobs.  The PRODUCT library reads no environment variable of its own: what an embedding application or a test
+// may change goes through qa_set_option (include/qaray_hip.h).  Builds made with -DQA_DEV_KNOBS (make hip EXTRA=-DQA_DEV_KNOBS,
+// the A/B scripts under tools/) additionally read the QA_* variables named at the call sites.
+inline const char *DevEnv(const char *name)
+{
+#ifdef QA_DEV_KNOBS
+  return getenv(name);
+#else
+  (void) name;
+  return nullptr;
+#endif
+}
+
 struct EventPair { hipEvent_t a, b; };
 
 // Host side of the staged integrator (qa_wf.hip): buffers are kept between frames
 struct WfHost {
   bool eligible = false;        // the uploaded scene can run staged (SelectStaged)
   bool modeSet = false;         // qa_set_pipeline was called
-  int mode = 2;                 // QA_PIPELINE: 0 mega, 1 staged, 2 auto (timed probe at the first large frame)
-  int decision = -1;            // auto: -1 not probed yet, 0 megakernel, 1 staged
-  float probeMs[2] = {0.f, 0.f};
+  int mode = 2;                 // qa_set_pipeline: 0 mega, 1 staged, 2 auto (= the megakernel: the staged integrator runs on request only)
   int numLights = 0;            // non-ambient lights
   int32_t lightIdx[QA_WF_MAX_LIGHTS] = {0, 0, 0, 0};
   // The frame's 8x8 tiles are dealt round-robin to a few GROUPS; each group has its own slot state, queues and counters
@@ -50,9 +61,7 @@ struct WfHost {
   };
   static const int kMaxGroups = 8;
   Group groups[kMaxGroups];
-  int numGroups = 1;            // 4 when the process has >= 8 hardware queues (GPU_MAX_HW_QUEUES), else 1; QA_WF_GROUPS overrides
-  bool probing = false;         // Render() is timing the two integrators on a sample of the region
-  int probeWhich = 0, probeSpp = 0, probeStep = 1;
+  int numGroups = 1;            // qa_set_option("staged_groups"): several groups only pay when the process has a hardware queue per group stream (GPU_MAX_HW_QUEUES >= 8)
   hipEvent_t start = nullptr;
   hipStream_t redoStream = nullptr;   // shared by the groups
   bool redoAsync = true;              // QA_WF_REDO_ASYNC=0: wf_redo in the group's own chain
@@ -85,7 +94,7 @@ struct qa_ctx {
   int workNext = 0;
   int *hStop = nullptr;           // mapped host memory, read by the kernel's wave leaders
   int *dStopAlias = nullptr;
-  DCounters *dCounters = nullptr, *dCountersProbe = nullptr;
+  DCounters *dCounters = nullptr;
   // host-variant staging
   float *dRgb = nullptr, *dDepth = nullptr;
   uint32_t *dNs = nullptr;
@@ -122,7 +131,12 @@ struct qa_ctx {
   uint64_t photonEmitted[2] = {0, 0}, photonEmissions[2] = {0, 0};
   std::vector<qa_photon> hostPhotons[2];   // balanced, [0] unused
   WfHost wf;
-  std::string kernelName;
+  std::string kernelName;       // the integrator the next frame is planned to run on (SetKernelName)
+  std::string launchedName;     // what the last qa_render_* call really launched (empty before the first)
+  // qa_set_option
+  bool optCoop = true;          // "coop": cooperative mesh walks (qa_kernel_cs.h) where the scene allows them
+  uint32_t optCsPool = 0;       // "cs_pool_limit": upper bound for the walks' pool capacity (tests force the overflow path)
+  bool optVerbose = false;      // "verbose": tree / launch-shape report on stderr at upload
 };
 
 void FreePhotonMaps(qa_ctx *c);  // qa_photon.hip

@@ -137,12 +137,11 @@ void SelectStaged(qa_ctx *c)
   for (const DMesh &dm : c->hostMeshes) if (dm.num_faces > 0 && !dm.useWide) ok = false;
   if (!w.modeSet) {     // qa_set_pipeline outlives scene uploads; otherwise the environment decides
     w.mode = QA_PIPE_AUTO;
-    if (const char *e = getenv("QA_PIPELINE")) {
+    if (const char *e = DevEnv("QA_PIPELINE")) {
       if (!strcmp(e, "mega")) w.mode = QA_PIPE_MEGA;
       else if (!strcmp(e, "staged")) w.mode = QA_PIPE_STAGED;
     }
   }
-  w.decision = -1;
   w.eligible = ok;
   w.numLights = ok ? nl : 0;
 }
@@ -182,8 +181,8 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     }
   }
   const uint32_t budget = w.budget;
-  const bool dbg = getenv("QA_WF_DEBUG") != nullptr;   // synchronise and report after every stage
-  const uint32_t refillAt = getenv("QA_WF_REFILL") ? (uint32_t) atoi(getenv("QA_WF_REFILL")) : 16u;
+  const bool dbg = DevEnv("QA_WF_DEBUG") != nullptr;   // synchronise and report after every stage
+  const uint32_t refillAt = DevEnv("QA_WF_REFILL") ? (uint32_t) atoi(DevEnv("QA_WF_REFILL")) : 16u;
 
   // ---- per-group buffers and launch shapes
   struct Shape { unsigned initBlocks, logicBlocks, cullBlocks, traceBlocks, redoBlocks; };
@@ -212,13 +211,13 @@ int RenderStaged(qa_ctx *c, const DScene &ds, const RenderParams &rp, hipStream_
     b.numLights = (uint32_t) w.numLights;
     for (int j = 0; j < QA_WF_MAX_LIGHTS; ++j) b.lightIdx[j] = w.lightIdx[j];
     b.refillAt = refillAt;
-    b.reserve = getenv("QA_WF_RESERVE") ? (uint32_t) std::max(64, atoi(getenv("QA_WF_RESERVE"))) : 128u;   // 64 / 128 / 256 @ 64 spp: C3 313 / 324 / 316, C4 1522 / 1473 / 1370, C5 810 / 815 / 791 Msamples/s
-    b.debug = dbg ? (uint32_t) atoi(getenv("QA_WF_DEBUG")) >> 1 : 0u;
+    b.reserve = DevEnv("QA_WF_RESERVE") ? (uint32_t) std::max(64, atoi(DevEnv("QA_WF_RESERVE"))) : 128u;   // 64 / 128 / 256 @ 64 spp: C3 313 / 324 / 316, C4 1522 / 1473 / 1370, C5 810 / 815 / 791 Msamples/s
+    b.debug = dbg ? (uint32_t) atoi(DevEnv("QA_WF_DEBUG")) >> 1 : 0u;
     const size_t rays = slots * (1 + b.numLights);
     Shape &sh = shape[gi];
     sh.initBlocks = (unsigned) std::max<size_t>(1, (slots + QA_BLOCK - 1) / QA_BLOCK);
     const size_t slice = (size_t) c->numCUs * (size_t) perCU;
-    const size_t logicSlice = getenv("QA_WF_LOGIC_BLOCKS") ? (size_t) c->numCUs * (size_t) atoi(getenv("QA_WF_LOGIC_BLOCKS")) : slice;
+    const size_t logicSlice = DevEnv("QA_WF_LOGIC_BLOCKS") ? (size_t) c->numCUs * (size_t) atoi(DevEnv("QA_WF_LOGIC_BLOCKS")) : slice;
     sh.logicBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? logicSlice : (size_t) c->numCUs * 8, sh.initBlocks));
     sh.cullBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(G > 1 ? slice : (size_t) c->numCUs * 8, (rays + QA_BLOCK - 1) / QA_BLOCK));
     sh.traceBlocks = (unsigned) std::max<size_t>(1, std::min<size_t>(slice, (rays + QA_BLOCK - 1) / QA_BLOCK));

@@ -93,7 +93,6 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
                           const uint32_t *nsamples, int sppMax, bool useSRGB)
 {
   const int cw = x1 - x0;
-  int deposited = 0;
   for (int j = y0; j < y1; ++j)
     for (int i = x0; i < x1; ++i) {
       const size_t q = (size_t) (j - y0) * cw + (i - x0);
@@ -101,7 +100,6 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
       // nsamples = 0: the pixel was skipped (tasking::signal_stop); the reference leaves such pixels untouched,
       // mask 0 (src/renderers/renderer.cpp:365,402)
       if (nsamples[q] == 0) continue;
-      ++deposited;
       float c[3] = {rgb[3 * q], rgb[3 * q + 1], rgb[3 * q + 2]};
       for (int k = 0; k < 3; ++k) {
         if (useSRGB) c[k] = LinearToSRGB(c[k]);
@@ -113,7 +111,9 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
       sampleCount[idx] = static_cast<uint8_t>(255.f * nsamples[q] / static_cast<float>(sppMax));
       mask[idx] = 1;
     }
-  IncrementNumRenderPixel(deposited);
+  // the reference counts every pixel of a tile it has been through, rendered or skipped by a stop request
+  // (src/renderers/renderer.cpp:399-404), so IsRenderDone() turns true after a stopped frame as well
+  IncrementNumRenderPixel((x1 > x0 && y1 > y0) ? cw * (y1 - y0) : 0);
 }
 
 namespace tasking {

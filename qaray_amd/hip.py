@@ -6,10 +6,8 @@ import os
 
 import numpy as np
 
-# The staged integrator overlaps the stage kernels of four tile groups on four HIP streams; with the runtime's default of
-# four hardware queues per process those streams (plus the caller's) share queues and their kernels serialise.  Ask for
-# eight before the HIP runtime initialises (it reads the variable at its first call; harmless if it is already up).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (No environment variable is changed here.  The staged integrator's tile groups - Context.set_option("staged_groups", 4) -
+# only pay when the PROCESS exported GPU_MAX_HW_QUEUES=8 before the HIP runtime initialised: bench.py and the tools do.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("QA_HIP_LIB") or os.path.join(_HERE, "lib", "libqaray_hip.so")  # QA_HIP_LIB: A/B builds
@@ -84,6 +82,7 @@ def lib():
         L.qa_reset_kernel_time.argtypes = [C.c_void_p]
         L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.qa_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.qa_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
         L.qa_get_kernel_name.argtypes = [C.c_void_p]
         L.qa_get_kernel_name.restype = C.c_char_p
         L.qa_get_staged_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -244,8 +243,12 @@ class Context:
     PIPELINES = {"mega": 0, "staged": 1, "auto": 2}
 
     def set_pipeline(self, mode):
-        """'mega' | 'staged' | 'auto': which integrator renders scenes that do not fit LDS (same bits either way)."""
+        """'mega' | 'staged' | 'auto' (= mega): which integrator renders scenes that do not fit LDS (same bits either way)."""
         _check(lib().qa_set_pipeline(self._h, self.PIPELINES[mode]))
+
+    def set_option(self, name, value):
+        """qa_set_option: 'coop', 'cs_pool_limit', 'sync_samples', 'tile_order', 'staged_groups', 'verbose'."""
+        _check(lib().qa_set_option(self._h, name.encode(), int(value)))
 
     def kernel_name(self):
         """The integrator the uploaded scene runs on (megakernel variant or the staged pipeline)."""

@@ -6,6 +6,9 @@ import sys
 import numpy as np
 import pytest
 
+# the staged integrator's tile groups want a hardware queue per stream; the HIP runtime reads this at its first call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -209,7 +209,7 @@ def test_big_fuzz_meshes_all_searches_agree(ctx, tmp_path, kind, seed):
 @pytest.mark.parametrize("case", ["tower", "object", "sheets"])
 def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
     """qa_integrate_cs (the whole wave walks the closest-hit and shadow queries of a mesh from a pool in LDS, qa_kernel_cs.h)
-    against qa_integrate (every lane walks its own ray; QA_COOP=0 at upload) and the counting kernel (reference tree, walked
+    against qa_integrate (every lane walks its own ray; option "coop" = 0) and the counting kernel (reference tree, walked
     as the reference walks it): same bits, same cast counts.  The coincident sheets make equal-distance accepts from
     different lanes in one round - the case the 64-bit key's return value has to catch."""
     from qaray_amd import hip
@@ -224,26 +224,20 @@ def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
         blob = load_scene_blob("trc_scene_tower.xml" if case == "tower" else "example_project7_object.xml", size=size)
     w, h = size
     outs, cnts, names = {}, {}, {}
-    old = os.environ.get("QA_COOP")
-    try:
-        for mode in ("coop", "tiny", "own", "stats"):
-            if mode == "own": os.environ["QA_COOP"] = "0"
-            else: os.environ.pop("QA_COOP", None)
-            # "tiny": a pool of 64 items overflows constantly - those rays must come back from the exact repeat unchanged
-            if mode == "tiny": os.environ["QA_CS_POOL"] = "64"
-            else: os.environ.pop("QA_CS_POOL", None)
-            c = hip.Context(0)
-            c.upload_scene(blob)
-            c.set_pipeline("mega")
-            c.reset_counters()
-            outs[mode] = c.render_region((0, 0, w, h), spp, stats=(mode == "stats"))
-            cnts[mode] = c.counters()
-            names[mode] = c.kernel_name()
-            c.close()
-    finally:
-        os.environ.pop("QA_CS_POOL", None)
-        if old is None: os.environ.pop("QA_COOP", None)
-        else: os.environ["QA_COOP"] = old
+    for mode in ("coop", "tiny", "own", "stats"):
+        c = hip.Context(0)
+        c.set_option("coop", 0 if mode == "own" else 1)
+        # "tiny": a pool of 64 items overflows constantly - those rays must come back from the exact repeat unchanged
+        c.set_option("cs_pool_limit", 64 if mode == "tiny" else 0)
+        c.upload_scene(blob)
+        c.set_pipeline("mega")
+        c.reset_counters()
+        names[mode] = c.kernel_name()
+        outs[mode] = c.render_region((0, 0, w, h), spp, stats=(mode == "stats"))
+        cnts[mode] = c.counters()
+        if mode == "stats":
+            assert "counting variant" in c.kernel_name(), c.kernel_name()   # the name of what was launched
+        c.close()
     assert "qa_integrate_cs" in names["coop"] and "qa_integrate_cs" in names["tiny"] and "qa_integrate_cs" not in names["own"], names
     for mode in ("coop", "tiny", "own"):
         for a, b in zip(outs[mode], outs["stats"]):
@@ -310,56 +304,76 @@ def test_staged_tile_groups_on_streams_equal_the_megakernel(ctx, scene):
     ctx.reset_counters()
     ref = ctx.render_region((0, 0, W, H), spp)
     cref = ctx.counters()
+    ctx.set_option("staged_groups", 4)
     ctx.set_pipeline("staged")
-    for _ in range(2):
-        ctx.reset_counters()
-        out = ctx.render_region((0, 0, W, H), spp)
-        c = ctx.counters()
-        for a, b in zip(out, ref):
-            assert np.array_equal(bits(a), bits(b))
-        assert c == cref
+    assert "4 tile groups" in ctx.kernel_name()
+    try:
+        for _ in range(2):
+            ctx.reset_counters()
+            out = ctx.render_region((0, 0, W, H), spp)
+            c = ctx.counters()
+            for a, b in zip(out, ref):
+                assert np.array_equal(bits(a), bits(b))
+            assert c == cref
+    finally:
+        ctx.set_option("staged_groups", 1)
 
 
-def test_auto_probe_picks_an_integrator_and_keeps_the_bits():
-    """QA_PIPE_AUTO.  With cooperative walks (the default) the megakernel is kept without a probe.  Without them
-    (QA_COOP=0 at upload) the first large frame (>= 128 spp, >= 0.5 Mpixel) is preceded by timed 32-spp renders by both
-    integrators; whatever it picks, the frame equals the megakernel's, and the probe leaves the counters alone."""
+def test_auto_is_the_megakernel_and_staged_runs_on_request_only():
+    """QA_PIPE_AUTO keeps the megakernel (round 2's timed probe between the integrators is gone: the staged integrator
+    lost on every scene and stays as a cross-check); the name reported after a frame is the kernel that frame ran on."""
     from qaray_amd import hip
     from qaray_amd.host import load_scene_blob
     ensure_assets()
-    W, H, spp = 1280, 720, 128
+    W, H, spp = 640, 360, 8
     blob = load_scene_blob("trc_scene_tower.xml", size=(W, H))
-    old = os.environ.get("QA_COOP")
-    try:
-        os.environ.pop("QA_COOP", None)
-        c = hip.Context(0)
-        c.upload_scene(blob)
-        c.set_pipeline("auto")
-        assert "qa_integrate_cs" in c.kernel_name() and "probe" not in c.kernel_name(), c.kernel_name()
-        ref = c.render_region((0, 0, W, H), spp)
-        assert "qa_integrate_cs" in c.kernel_name() and "probe" not in c.kernel_name(), c.kernel_name()
-        c.close()
-        os.environ["QA_COOP"] = "0"
-        c = hip.Context(0)
-        c.upload_scene(blob)
-        c.set_pipeline("auto")
-        assert "probe" in c.kernel_name() and "decided" in c.kernel_name()
-        c.reset_counters()
-        a = c.render_region((0, 0, W, H), spp)
-        ca = c.counters()
-        assert "probe at 32 spp: megakernel" in c.kernel_name()
-        assert ca["samples"] == W * H * spp and ca["pixels"] == W * H
-        c.set_pipeline("mega")
-        c.reset_counters()
-        b = c.render_region((0, 0, W, H), spp)
-        cb = c.counters()
-        c.close()
-    finally:
-        if old is None: os.environ.pop("QA_COOP", None)
-        else: os.environ["QA_COOP"] = old
-    for x, y, z in zip(a, b, ref):
+    c = hip.Context(0)
+    c.upload_scene(blob)
+    c.set_pipeline("auto")
+    assert "qa_integrate_cs" in c.kernel_name()
+    a = c.render_region((0, 0, W, H), spp)
+    assert "qa_integrate_cs" in c.kernel_name() and "probe" not in c.kernel_name()
+    c.set_option("coop", 0)
+    assert c.kernel_name().startswith("qa_integrate<RES=0")
+    b = c.render_region((0, 0, W, H), spp)
+    assert c.kernel_name().startswith("qa_integrate<RES=0")
+    c.set_pipeline("staged")
+    assert c.kernel_name().startswith("staged") and "1 tile group" in c.kernel_name()
+    s_ = c.render_region((0, 0, W, H), spp)
+    assert c.kernel_name().startswith("staged")
+    # a frame the staged integrator refuses (counting kernel) is named after what really ran
+    c.render_region((0, 0, 64, 64), 1, stats=True)
+    assert c.kernel_name().startswith("qa_integrate<") and "counting variant" in c.kernel_name()
+    c.close()
+    for x, y, z in zip(a, b, s_):
         assert np.array_equal(bits(x), bits(y)) and np.array_equal(bits(x), bits(z))
-    assert ca == cb
+
+
+def test_more_than_32_lights_keep_the_per_lane_kernel(tmp_path):
+    """csShadows keeps one occlusion bit per non-ambient light in a 32-bit mask; a scene with 33 lights over a global-memory
+    mesh must not take the cooperative kernel (lights 32.. would alias onto earlier bits), and renders like the oracle."""
+    from oracle import binding as oracle
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    xml = _write_big_fuzz_scene(str(tmp_path), np.random.default_rng(5), "shell")
+    txt = open(xml).read()
+    lights = "".join('<light type="point" name="p%d"><intensity value="6"/><position x="%g" y="%g" z="%g"/></light>\n' %
+                     (i, 9 * np.cos(0.7 * i), -9 + 3 * np.sin(1.3 * i), 6 + (i % 5)) for i in range(32))
+    txt = txt.replace('<light type="direct"', lights + '<light type="direct"')
+    open(xml, "w").write(txt)
+    w, h, spp = 96, 72, 2
+    blob = load_scene_blob(xml, size=(w, h), asset_root=str(tmp_path))
+    c = hip.Context(0)
+    c.upload_scene(blob)
+    assert c.kernel_name().startswith("qa_integrate<RES=0"), c.kernel_name()   # 34 non-ambient lights
+    c.reset_counters()
+    rgb, depth, ns = c.render_region((0, 0, w, h), spp)
+    cnt = c.counters()
+    c.close()
+    o = oracle.render(blob, (0, 0, w, h), spp)
+    assert np.array_equal(bits(depth), bits(o[1])) and np.array_equal(ns, o[2])
+    assert (cnt["casts_normal"], cnt["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
+    assert rmse(np.nan_to_num(rgb), np.nan_to_num(o[0])) <= RMSE_TOL
 
 
 def test_stop_request_ends_a_staged_frame(ctx):

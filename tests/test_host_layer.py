@@ -221,6 +221,20 @@ def test_framebuffer_postprocess_matches_reference_formula():
     assert fb.mask.all() and fb.num_rendered_pixels == 8
 
 
+def test_deposit_of_a_stopped_frame_counts_the_region_and_leaves_skipped_pixels_alone():
+    """After tasking::signal_stop the reference skips PixelRender but still adds the tile's pixel count
+    (src/renderers/renderer.cpp:399-404): GetNumRenderedPixels reaches width*height, skipped pixels keep mask 0."""
+    fb = FrameBuffer(4, 2)
+    rgb = np.full((2, 4, 3), 0.5, np.float32)
+    depth = np.ones((2, 4), np.float32)
+    ns = np.array([[4, 0, 4, 0], [0, 0, 4, 4]], np.uint32)   # 0 = skipped by the stop request
+    fb.deposit(0, 0, 4, 2, rgb, depth, ns, 4, use_srgb=False)
+    assert fb.num_rendered_pixels == 8
+    assert np.array_equal(fb.mask, (ns != 0).astype(np.uint8))
+    assert (fb.pixels[ns == 0] == 0).all() and (fb.zbuffer[ns == 0] == 0).all()
+    fb.close()
+
+
 def test_tasking_entry_points_keep_the_reference_signatures():
     """src/tasking/parallel_for.h:59-68 through the C ABI: thread count, parallel_for (every index once), stop flag."""
     import ctypes as C

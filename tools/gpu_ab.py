@@ -26,6 +26,9 @@ for name, env in variants:
     for k in KNOBS: os.environ.pop(k, None)
     os.environ.update(env)
     ctx = hip.Context(0)
+    # the product library reads no QA_* variable (only -DQA_DEV_KNOBS builds do): the two common ones go through the API
+    if "QA_PIPELINE" in env: ctx.set_pipeline(env["QA_PIPELINE"])
+    if "QA_COOP" in env: ctx.set_option("coop", int(env["QA_COOP"]))
     for tag in cases:
         scene, size, spp = CASES[tag]
         spp = spp_override or spp
@@ -34,6 +37,8 @@ for name, env in variants:
         ctx.reset_counters()
         out = ctx.render_region((0, 0) + small, 4)
         res[(name, tag)] = (out, ctx.counters())
+        import hashlib
+        sha = hashlib.sha1(b"".join(np.ascontiguousarray(x).tobytes() for x in out)).hexdigest()[:12]
         ctx.upload_scene(load_scene_blob(scene, size=size))
         ctx.render_region((0, 0, 64, 64), 1)
         ctx.reset_kernel_time(); ctx.reset_counters()
@@ -41,7 +46,7 @@ for name, env in variants:
         ms, _ = ctx.kernel_time(); c = ctx.counters()
         casts = c["casts_normal"] + c["casts_shadow"]
         line = (f"{name:10s} {tag}: {size[0]}x{size[1]} @ {spp} spp: {ms:8.1f} ms, {c['samples'] / ms * 1e-3:7.1f} Msamples/s, "
-                f"{casts / ms * 1e-6:.2f} Gcasts/s  [{ctx.kernel_name()[:24]}]")
+                f"{casts / ms * 1e-6:.2f} Gcasts/s  [{ctx.kernel_name()[:24]}] small-frame sha1 {sha}")
         if "staged" in ctx.kernel_name():
             st = ctx.staged_stats()
             line += (f" passes {st['passes']} jobs {st['jobs_done']} steps/job {(st['node_steps'] + st['leaf_steps']) / max(1, st['jobs_done']):.1f} "
