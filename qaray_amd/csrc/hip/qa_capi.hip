@@ -61,16 +61,6 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
   return stats ? PickShading<false, true>(lights, tex, area) : PickShading<false, false>(lights, tex, area);
 }
 
-static int NonAmbientLights(const qa_ctx *c)
-{
-  if (c->hostBlob.size() < sizeof(qa_flat_header)) return 0;
-  const qa_flat_header *h = reinterpret_cast<const qa_flat_header *>(c->hostBlob.data());
-  const qa_light *light = QA_BLOB_PTR(qa_light, c->hostBlob.data(), h->off_lights);
-  int n = 0;
-  for (uint32_t i = 0; i < h->num_lights; ++i) n += light[i].type != QA_LIGHT_AMBIENT;
-  return n;
-}
-
 static const char *kStagedName = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
 static std::string MegaName(const qa_ctx *c, bool cs)
 {
@@ -104,22 +94,22 @@ static int SelectKernel(qa_ctx *c)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
   // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
-  // csShadows keeps one occlusion bit per non-ambient light in a 32-bit mask: scenes with more lights keep qa_integrate.
+  // (any number of lights: their shadow queries are pooled four lights at a time, qa_kernel_cs.h csDirectLight)
   c->kernelCs = nullptr;
   {
     const char *e = DevEnv("QA_COOP");
-    if (!c->resident && !c->area && c->csFits && c->stackDepth * 64u >= 192u + 512u && c->optCoop && NonAmbientLights(c) <= 32 && !(e && !strcmp(e, "0"))) {
+    if (!c->resident && !c->area && c->csFits && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
       c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true> : (KernelFn) qa_integrate_cs<true, false>)
                            : (c->textured ? (KernelFn) qa_integrate_cs<false, true> : (KernelFn) qa_integrate_cs<false, false>);
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytes) != hipSuccess || n < 1) n = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytesCs) != hipSuccess || n < 1) n = 2;
       c->blocksPerCUCs = n > 8 ? 8 : n;
     }
   }
   SetKernelName(c);
   if (c->optVerbose || DevEnv("QA_FAST_VERBOSE"))
-    fprintf(stderr, "kernel %s: dynamic LDS %zu B per workgroup (stack depth %u), workgroups per CU: megakernel %d, cooperative %d\n", c->kernelName.c_str(),
-            c->ldsBytes, c->stackDepth, c->blocksPerCUAuto, c->kernelCs ? c->blocksPerCUCs : 0);
+    fprintf(stderr, "kernel %s: dynamic LDS per workgroup: megakernel %zu B (stack depth %u), cooperative %zu B (%u pool items, %u ray slots per wave); workgroups per CU: megakernel %d, cooperative %d\n",
+            c->kernelName.c_str(), c->ldsBytes, c->stackDepth, c->ldsBytesCs, c->ds.csItems, c->ds.csSlots, c->blocksPerCUAuto, c->kernelCs ? c->blocksPerCUCs : 0);
   return QA_OK;
 }
 
@@ -242,6 +232,7 @@ static int PrepareScene(qa_ctx *c)
       }
     }
     if (stackNeed > stackNeedMax) stackNeedMax = stackNeed;
+    const uint32_t stackNeedRef = stackNeed;   // depth of the reference tree alone
     std::vector<DTri> &dt = allTris[mi];
     std::vector<DTriShade> &dsh = allShade[mi];
     dt.resize(m.num_faces);
@@ -473,7 +464,9 @@ static int PrepareScene(qa_ctx *c)
     dm.wrootWord = allWide[mi].rootWord;
     dm.wideStack = 3 * allWide[mi].depth + 2;
     dm.wnodeCount = (uint32_t) allWide[mi].nodes.size();
-    if (dm.wnodeCount > QA_CS_INDEX_MASK || m.num_faces > QA_CS_INDEX_MASK) csFits = false;
+    if (m.num_faces > QA_CS_INDEX_MASK) csFits = false;          // a key holds instance << 20 | element (qa_kernel_cs.h)
+    if (stackNeedRef > QA_CS_EXACT_STACK) csFits = false;        // private stacks of the exact walks
+    if (textured && m.num_faces > 0 && !dm.hasVT) csFits = false;   // a hit there keeps the uvw of an earlier, farther hit: history only a sequential walk has
     dm.nearPad = meshSlack[mi].nearPad;
     dm.cancelDist = meshSlack[mi].cancelDist;
     {
@@ -558,6 +551,96 @@ static int PrepareScene(qa_ctx *c)
   ds.mtlset = QA_BLOB_PTR(qa_mtlset, c->dBlob, h->off_mtlsets);
   ds.light = QA_BLOB_PTR(qa_light, c->dBlob, h->off_lights);
   int rc;
+  // ---- qa_integrate_cs: the 4-wide trees of all meshes in one node array and one triangle array (qa_kernel_cs.h) -------------
+  {
+    std::vector<DWideNode> csNodes;
+    std::vector<DTri> csTris;
+    std::vector<float> csLeafBox;   // 8 floats per triangle of csTris: box of its leaf in the reference tree, 1.0f = that leaf is the root
+    try {
+      for (uint32_t mi = 0; mi < h->num_meshes; ++mi) {
+        const WideBvh &wb = allWide[mi];
+        const uint32_t nodeBase = (uint32_t) csNodes.size(), triBase = (uint32_t) csTris.size();
+        auto rebase = [&](uint32_t w) -> uint32_t {
+          if (w == QA_DONE) return w;
+          if (w & QA_BVH_LEAF_BIT) return (w & ~QA_BVH_OFFSET_MASK) | ((w & QA_BVH_OFFSET_MASK) + triBase);
+          return w + nodeBase;
+        };
+        for (const DWideNode &nd : wb.nodes) {
+          DWideNode d = nd;
+          for (int q = 0; q < 4; ++q) d.child[q] = rebase(nd.child[q]);
+          csNodes.push_back(d);
+        }
+        const qa_bvh_node *rnodes = QA_BLOB_PTR(qa_bvh_node, blob, mesh[mi].off_bvh_nodes);
+        for (size_t i = 0; i < allWTris[mi].size(); ++i) {
+          csTris.push_back(allWTris[mi][i]);
+          const uint32_t leaf = allShade[mi][wb.order[i]].pad;
+          float rec[8] = {0, 0, 0, 0, 0, 0, leaf <= 1 ? 1.0f : 0.0f, 0};
+          if (leaf < mesh[mi].num_bvh_nodes) memcpy(rec, rnodes[leaf].box, 24);
+          csLeafBox.insert(csLeafBox.end(), rec, rec + 8);
+        }
+        dmeshes[mi].csRootWord = rebase(wb.rootWord);
+      }
+    } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+    if (csNodes.size() > QA_CS_INDEX_MASK || csTris.size() > QA_CS_INDEX_MASK || h->num_instances > 256) csFits = false;
+    if (h->width > 0xFFFFu || h->height > 0xFFFFu || h->num_materials > 0xFFFEu) csFits = false;   // pixel and material ride in 16-bit halves of the kernel's state words
+    if (csFits && !csTris.empty()) {
+      const DWideNode *dn = nullptr;
+      const DTri *dtr = nullptr;
+      const float *dlb = nullptr;
+      if (csNodes.empty()) csNodes.push_back(DWideNode{});
+      if ((rc = DeviceCopy(c, csNodes, &dn)) != QA_OK) return rc;
+      if ((rc = DeviceCopy(c, csTris, &dtr)) != QA_OK) return rc;
+      if ((rc = DeviceCopy(c, csLeafBox, &dlb)) != QA_OK) return rc;
+      c->csNodesDev = reinterpret_cast<const uint4 *>(dn);
+      c->csTrisDev = reinterpret_cast<const uint4 *>(dtr);
+      c->csLeafBoxDev = reinterpret_cast<const uint4 *>(dlb);
+    } else csFits = false;
+  }
+  // one flat record per scene-graph node for qa_integrate_cs's sweeps
+  {
+    static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+    if (!(memcmp(inst[0].tm, I9, 36) == 0 && memcmp(inst[0].itm, I9, 36) == 0 && memcmp(inst[0].pos, Z3, 12) == 0)) csFits = false;   // (XML scenes: always the identity)
+    std::vector<CsInst> ci(h->num_instances);
+    memset(ci.data(), 0, ci.size() * sizeof(CsInst));
+    for (uint32_t k = 1; k < h->num_instances; ++k) {
+      const qa_instance &in = inst[k];
+      CsInst &r = ci[k];
+      r.type = in.obj_type;
+      r.depth = in.depth;
+      r.parent = in.parent;
+      if (in.obj_type == QA_OBJ_NONE) continue;
+      if (in.depth < 1 || in.depth > 2) { csFits = false; continue; }
+      const qa_instance &a = in.depth == 2 ? inst[in.parent] : in;
+      memcpy(r.itmA, a.itm, 36); memcpy(r.posA, a.pos, 12); memcpy(r.tmA, a.tm, 36);
+      if (in.depth == 2) { memcpy(r.itmB, in.itm, 36); memcpy(r.posB, in.pos, 12); memcpy(r.tmB, in.tm, 36); }
+      double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};   // sphere: the unit ball; plane: the unit square at z = 0
+      if (in.obj_type == QA_OBJ_PLANE) lo[2] = hi[2] = 0;
+      if (in.obj_type == QA_OBJ_MESH) {
+        const DMesh &dm = dmeshes[in.mesh];
+        r.mesh = (uint32_t) in.mesh;
+        r.useWide = dm.useWide;
+        r.csRootWord = dm.csRootWord;
+        r.num_faces = dm.num_faces;
+        memcpy(r.bmin, dm.bmin, 12); memcpy(r.bmax, dm.bmax, 12);
+        r.nearPad = dm.nearPad; r.absMax = dm.absMax; r.cancelDist = dm.cancelDist;
+        for (int q = 0; q < 3; ++q) { lo[q] = dm.bmin[q]; hi[q] = dm.bmax[q]; }
+      }
+      // bounds in root space: the eight corners through tm * p + pos of every level (double), padded below
+      double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+      for (int corner = 0; corner < 8; ++corner) {
+        double pnt[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+        for (int lvl = in.depth; lvl >= 1; --lvl) {
+          const qa_instance &t = (lvl == in.depth) ? in : inst[in.parent];
+          double o[3];
+          for (int rr = 0; rr < 3; ++rr) o[rr] = (double) t.tm[rr] * pnt[0] + (double) t.tm[3 + rr] * pnt[1] + (double) t.tm[6 + rr] * pnt[2] + (double) t.pos[rr];
+          memcpy(pnt, o, sizeof(o));
+        }
+        for (int q = 0; q < 3; ++q) { wlo[q] = std::min(wlo[q], pnt[q]); whi[q] = std::max(whi[q], pnt[q]); }
+      }
+      for (int q = 0; q < 3; ++q) { r.wmin[q] = (float) wlo[q]; r.wmax[q] = (float) whi[q]; }
+    }
+    if ((rc = DeviceCopy(c, ci, &c->csInstDev)) != QA_OK) return rc;
+  }
   if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
   c->hostMeshes = dmeshes;
   if ((rc = DeviceCopy(c, dmat, &ds.mtl)) != QA_OK) return rc;
@@ -626,6 +709,17 @@ static int PrepareScene(qa_ctx *c)
     for (uint32_t k = 0; k < h->num_meshes; ++k) ds.meshv[k] = dmeshes[k];
   }
   c->ldsBytes = stackBytes + (c->resident ? imageBytes : 0);
+  // qa_integrate_cs: per wave [ray slots | results | flags | pool items | accumulators]; four workgroups per CU (160 KB LDS)
+  ds.csNodes = c->csNodesDev;
+  ds.csTris = c->csTrisDev;
+  ds.csLeafBox = c->csLeafBoxDev;
+  ds.csInst = c->csInstDev;
+  ds.csItems = DevEnv("QA_CS_ITEMS") ? (uint32_t) atoi(DevEnv("QA_CS_ITEMS")) : 896u;
+  ds.csSlots = DevEnv("QA_CS_SLOTS") ? (uint32_t) atoi(DevEnv("QA_CS_SLOTS")) : 112u;
+  if (ds.csSlots < 64u) ds.csSlots = 64u;     // an instance enters up to 64 rays at once
+  if (ds.csSlots > 256u) ds.csSlots = 256u;   // 8 bits of an item
+  if (ds.csItems < 128u) ds.csItems = 128u;
+  c->ldsBytesCs = (size_t) CsLdsWords(ds.csItems, ds.csSlots) * (QA_BLOCK / 64) * sizeof(uint32_t);
   memcpy(ds.cam.screenA, h->screenA, 12);
   memcpy(ds.cam.screenU, h->screenU, 12);
   memcpy(ds.cam.screenV, h->screenV, 12);
@@ -742,7 +836,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (pmOn) ds.stackDepth = c->stackDepthPm;
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
   ds.csPoolLimit = DevEnv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(DevEnv("QA_CS_POOL"))) : c->optCsPool;
-  const size_t ldsBytes = pmOn ? c->ldsBytesPm : c->ldsBytes;
+  const size_t ldsBytes = pmOn ? c->ldsBytesPm : (cs ? c->ldsBytesCs : c->ldsBytes);
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
                                : ((flags & QA_RENDER_STATS) ? c->kernelStats : (cs ? c->kernelCs : c->kernel));
 
@@ -1060,8 +1154,11 @@ int qa_get_counters(qa_ctx *c, qa_counters *out)
             "direct light %.3f (shadow mesh walks %.3f), sample end %.3f, miss branch %.3f, hit before shading %.3f, spawn %.3f\n", h.stamp[9], h.stamp[8] / w, k / w, h.stamp[1] / k, h.stamp[2] / k, h.stamp[3] / k,
             h.stamp[4] / k, h.stamp[5] / k, h.stamp[6] / k, h.stamp[7] / k, h.stamp[10] / k, h.stamp[11] / k, h.stamp[12] / k);
     if (c->kernelCs && h.stamp[11])   // qa_integrate_cs reuses slots 10 / 11: items taken from the pool / rounds of the cooperative walks
-      fprintf(stderr, "[stamps] cooperative walks: %llu rounds, %.1f of 64 lanes hold an item on average (lane occupancy of the walks %.3f); %.3f of the rounds hold <= 16 items\n", h.stamp[11],
+      fprintf(stderr, "[stamps] cooperative walks: %llu rounds, %.1f of 64 lanes hold an item on average (lane occupancy of the walks %.3f); %.3f of the rounds are leaf rounds; 'mesh walks' above = the rounds alone\n", h.stamp[11],
               (double) h.stamp[10] / (double) h.stamp[11], (double) h.stamp[10] / (64.0 * (double) h.stamp[11]), (double) h.stamp[12] / (double) h.stamp[11]);
+    if (c->kernelCs)
+      fprintf(stderr, "[stamps] closest-hit sweeps without their rounds %.3f, winners' details %.3f, shadow sweeps without their rounds %.3f; lanes sent to the exact walks: %llu closest, %llu shadow (of %llu + %llu casts)\n",
+              (h.stamp[13] - (double) h.stamp[3]) / k, h.stamp[14] / k, (h.stamp[17] - (double) h.stamp[6]) / k, h.stamp[15], h.stamp[16], (unsigned long long) h.casts_normal, (unsigned long long) h.casts_shadow);
   }
 #endif
   return QA_OK;

@@ -119,7 +119,10 @@ struct qa_ctx {
   KernelFn kernelPm = nullptr, kernelPmStats = nullptr;
   // the megakernel with cooperative mesh walks (qa_kernel_cs.h): global-memory scenes without area lights
   KernelFn kernelCs = nullptr;
-  bool csFits = false;          // every wide tree's node indices and triangle offsets fit the pool's 22-bit item field
+  bool csFits = false;          // the scene fits qa_integrate_cs's limits (20-bit scene-wide node / triangle indices, <= 256 nodes, ...)
+  size_t ldsBytesCs = 0;
+  const uint4 *csNodesDev = nullptr, *csTrisDev = nullptr, *csLeafBoxDev = nullptr;   // scene allocations (freed with the scene)
+  const CsInst *csInstDev = nullptr;
   int blocksPerCUCs = 2;
   int blocksPerCUPm = 2;
   uint32_t stackDepthPm = 0;   // LDS stack entries per lane when the kd-tree gather runs on it

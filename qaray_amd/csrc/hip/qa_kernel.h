@@ -527,7 +527,8 @@ struct TriPick { uint32_t tri; float a, b; };  // accepted triangle (element ord
 // with non-strict box tests, and `tie` is raised when a triangle passes the inside test at exactly
 // the distance already held.  Returns whether a triangle was accepted; best = its element index in
 // the walked tree's order.  closest = false stops at the first accepted triangle.
-template <bool FAST, bool STATS, bool GMEM = false>
+// STRIDE: distance between a lane's stack entries (QA_BLOCK: the per-lane columns of the LDS stacks; 1: a private array).
+template <bool FAST, bool STATS, bool GMEM = false, int STRIDE = QA_BLOCK>
 __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, uint32_t rootData, const Ray &ray, f3 drcp,
                                         bool fastSlab, float &hz, bool closest, uint32_t *stack, DCounters &cnt,
                                         uint32_t &best, bool &tie, float pad = 0.f)
@@ -567,11 +568,11 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
       if (hit0 && hit1) {
         // the reference pushes the far child, then the near one, and pops the near one next
         const bool nearFirst = entry0 < entry1;
-        stack[(sp++) * QA_BLOCK] = nearFirst ? d1 : d0;
+        stack[(sp++) * STRIDE] = nearFirst ? d1 : d0;
         cur = nearFirst ? d0 : d1;
       } else if (hit0) cur = d0;
       else if (hit1) cur = d1;
-      else cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
+      else cur = sp ? stack[(--sp) * STRIDE] : QA_DONE;
     }
     if (cur == QA_DONE) break;
     // ---- leaf: its triangles in element order -----------------------------------------------
@@ -591,7 +592,7 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
         if (!closest) return true;
       }
     }
-    cur = sp ? stack[(--sp) * QA_BLOCK] : QA_DONE;
+    cur = sp ? stack[(--sp) * STRIDE] : QA_DONE;
   }
   return hasHit;
 }
@@ -684,7 +685,8 @@ __device__ __forceinline__ bool walkWide(const uint4 *wn, const uint4 *tris, uin
 // search goes wrong only if such a "hit" lies before the triangle's leaf box on the ray, i.e. on the segment from the
 // origin to the mesh bounds - which is never farther from any triangle than the origin's farthest corner of the
 // bounds, or the bounds' diagonal.
-__device__ __forceinline__ bool insideCancelReach(const DMesh &m, f3 o)
+template <class M>
+__device__ __forceinline__ bool insideCancelReach(const M &m, f3 o)
 {
   const f3 bmin = ld3(m.bmin), bmax = ld3(m.bmax);
   const f3 f = F3(qmax(qabs(o.x - bmin.x), qabs(o.x - bmax.x)), qmax(qabs(o.y - bmin.y), qabs(o.y - bmax.y)), qmax(qabs(o.z - bmin.z), qabs(o.z - bmax.z)));
@@ -1036,8 +1038,9 @@ struct Surface {
   bool selDiffuse;       // RandomSelectMtl returned DIFFUSE (photon-map gathers hang off this)
 };
 
-template <bool TEX>
-__device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const DScene &sc, const TexTables &tt, int mi, f3 N,
+// (S: anything with the material -> texmap table `mtlTex`: DScene, or the few words an out-of-line caller hands over)
+template <bool TEX, class S = DScene>
+__device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const S &sc, const TexTables &tt, int mi, f3 N,
                                                 f3 V, bool front, const TexHit &th, int bounceLeft, bool fromDiffuse,
                                                 uint32_t &rng)
 {
@@ -1225,9 +1228,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
 
   DCounters cnt = {};
 #ifdef QA_STAMPS
-  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][13];
+  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][QA_NSTAMPS];
   cnt.sl = s_stamps[threadIdx.x / 64];
-  if (__lane_id() < 13) cnt.sl[__lane_id()] = 0;
+  if (__lane_id() < QA_NSTAMPS) cnt.sl[__lane_id()] = 0;
 #endif
   QA_T(tKernel)
   TexTables tt;
@@ -1501,7 +1504,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   if (lane == 0) {
     cnt.sl[0] = __builtin_readcyclecounter() - tKernel;
     cnt.sl[9] = 1;
-    for (int i = 0; i < 13; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
+    for (int i = 0; i < QA_NSTAMPS; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
   }
 #endif
 }

@@ -1,23 +1,36 @@
-// qa_kernel_cs.h — the megakernel for scenes whose meshes live in global memory, with COOPERATIVE mesh walks.
+// qa_kernel_cs.h — the megakernel for scenes whose meshes live in global memory, with COOPERATIVE mesh walks from ONE pool
+// per query phase.
 //
-// Why.  Shadow queries are half of such a frame (cycle stamps, profiles/round02/megakernel_section_stamps.txt: 55 % of a
-// wave's time on project7_object, 33 % on the tower scene, are the mesh walks of shadow rays), and qa_integrate walks them
-// like everything else: per instance, with the 22 (9) of 64 lanes whose ray enters the bounds, for as long as the slowest
-// of them takes.  But an any-hit query has no order to keep: "occluded" means that SOME triangle the reference accepts is
-// reachable within t_max.  So here the wave walks the shadow rays of one (light, mesh instance) pair TOGETHER: the entered
-// lanes' roots go into a pool in LDS (the wave's share of the traversal stacks, idle at that moment); every round all 64
-// lanes pop one (owner, node) item each - a lane tests ANOTHER lane's ray, fetched from the owner's registers with
-// ds_bpermute - and push the children the ray enters (ballot + prefix, no atomics) or test the leaf's triangles; items of a
-// ray that is already settled are dropped.  Lane occupancy no longer depends on how many rays enter a mesh or on how
-// unequal their walks are.
-// What makes the answer the reference's is unchanged (hitMesh, qa_kernel.h): the accepted triangle's leaf in the reference
-// tree must pass the reference's strict box test against t_max (refReaches), a triangle at exactly t_max, a full pool, a
-// mesh without the 4-wide tree or an origin beyond the pruned search's reach repeat the query with the sequential walk
-// of the reference tree.  Closest-hit queries, shading and every random draw are qa_integrate's: frames are bit-identical.
+// Why.  On such scenes three quarters of qa_integrate's wave time are mesh walks entered with a third (or a seventh) of the
+// lanes and lasting as long as the slowest of them (profiles/round02/megakernel_section_stamps.txt).  Round 2 let the whole
+// wave walk ONE (ray type, light, mesh instance) at a time from a pool of (ray, node) items; what that left: a walk per
+// instance and light - 18 of them per hit on project7_object, each with its own start-up, its own underfilled first and last
+// rounds (35 % of all rounds held <= 16 items) - and 234 spilled registers for the rays and bookkeeping the lanes had to keep
+// for each other.  Here a query PHASE (the closest-hit query of the wave's 64 paths, or the shadow queries of a batch of
+// lights) fills one pool:
+//   * Sweep.  Every instance is visited once (wave-uniform loop, the reference's pre-order).  Spheres and planes are
+//     intersected on the spot.  A lane whose ray passes a mesh's bounding-box gate writes its NODE-LOCAL ray into a ray slot
+//     in LDS (32 bytes: origin, limit, direction, owner lane | instance or light | box padding) and pushes the mesh's root.
+//   * Rounds.  All 64 lanes pop one item each (node | ray slot), read the ray from its slot, and either test the node's four
+//     children and push the entered ones (ballot + prefix, no atomics) or test the leaf's triangles with the reference's
+//     arithmetic.  Items of every instance - and of every light - share the rounds; with <= 16 items four lanes share an item.
+//     The 4-wide trees of all meshes live in ONE node array and ONE triangle array (DScene::csNodes / csTris, child words
+//     rebased at upload), so an item needs no mesh descriptor.
+//   * Closest hit: one 64-bit key per lane, distance bits << 32 | instance << 20 | element, updated with ds_min_u64 by whoever
+//     accepts a triangle; every lane prunes and accepts against the distance half, so a hit in one instance shortens the
+//     walks of all others at once (distances are world-parametric: rays are not renormalised in node space).  The minimum
+//     over instances with the lower instance winning at equal distance IS the reference's sequential answer, provided the
+//     winner would also have been reached by the reference's walk (qa_wf.h's argument): checked below.
+//   * Any hit: the first accepted triangle of a (lane, light) pair is recorded and its remaining items die when popped.
+// What makes the answer the reference's is hitMesh's argument unchanged (qa_kernel.h): the accepted triangle's leaf in the
+// reference tree must pass the reference's strict box test at the found distance (t_max for a shadow ray); a triangle at
+// exactly the distance held, a full pool, a mesh without the 4-wide tree or an origin beyond the pruned search's reach send
+// the lane's query to the exact sequential walk of the whole scene graph on the reference's trees (csExactClosest /
+// csExactShadow: out of line, private stacks - a handful of rays per million).  Shading and every random draw are
+// qa_integrate's: frames are bit-identical.
 //
-// Replaces (reference file:line): GenLight::Shadow -> Scene::TraceNodeShadow (src/lights/lights.cpp:39-48,
-// src/scene/scene.cpp:35-46) with TriObj::IntersectRay / TraceBVHNode as the any-hit query (src/objects/objects.cpp:310-420);
-// everything else as qa_kernel.h.
+// Replaces (reference file:line): Scene::TraceNodeNormal / TraceNodeShadow (src/scene/scene.cpp:35-74), GenLight::Shadow
+// (src/lights/lights.cpp:39-48), TriObj::IntersectRay / TraceBVHNode (src/objects/objects.cpp:310-420); everything else as qa_kernel.h.
 #pragma once
 #include "qa_kernel.h"
 
@@ -28,8 +41,15 @@ namespace qa {
 #else
 #define QA_FILL(cnt) nullptr
 #endif
-#define QA_CS_OWNER_SHIFT 22            /* pool item = child word | owner lane << 22 (inner: node index, leaf: flag, count, offset) */
-#define QA_CS_INDEX_MASK 0x3FFFFFu      /* node indices / triangle offsets of a mesh must fit 22 bits (host check) */
+#define QA_CS_SLOT_SHIFT 20             /* pool item = child word | ray slot << 20 (inner: node index; leaf: flag, count - 1, triangle offset) */
+#define QA_CS_INDEX_MASK 0xFFFFFu       /* scene-wide node indices / triangle offsets must fit 20 bits (host check), elements of a mesh too */
+#define QA_CS_SLOT_MASK 0xFFu           /* <= 256 ray slots */
+#define QA_CS_LIGHT_BATCH 4             /* shadow queries are pooled for up to four lights at a time */
+#define QA_CS_EXACT_STACK 64            /* private stack entries of the exact walks (reference trees deeper than this keep qa_integrate) */
+#ifndef QA_CS_LEAF_ROUND
+#define QA_CS_LEAF_ROUND 48u           /* leaf items that make a leaf round go first */
+#endif
+#define QA_CS_RES_WORDS 256             /* per wave: 64 closest-hit keys (2 words each) or QA_CS_LIGHT_BATCH x 64 any-hit results */
 
 __device__ __forceinline__ void csWaveSync()
 {
@@ -38,84 +58,134 @@ __device__ __forceinline__ void csWaveSync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The wave's pool: entry i of wave w sits at pool[(i / 64) * QA_BLOCK + i % 64] with pool = LDS stacks + 64 w (the wave's
-// own columns of the per-lane stacks).  cap entries, then 64 result words (accepted element + 1) and 64 flag words.
-__device__ __forceinline__ uint32_t &csSlot(uint32_t *pool, uint32_t i) { return pool[(i >> 6) * QA_BLOCK + (i & 63u)]; }
+// The wave's share of the dynamic LDS (host: CsLdsWords in qa_capi.hip): [items | ray slots | results | flags | accumulators]
+struct CsLds {
+  uint32_t *items;               // [capItems]
+  uint4 *rays;                   // [2 * slots]: (origin.xyz, limit), (direction.xyz, meta)
+  uint32_t *res;                 // [QA_CS_RES_WORDS]
+  uint32_t *flags;               // [64] closest: != 0 = repeat this lane's query exactly; any-hit: bit j = light j of the batch
+  uint32_t capItems, slots;
+};
+__device__ __forceinline__ unsigned long long *csKeys(const CsLds &L) { return reinterpret_cast<unsigned long long *>(L.res); }
 
-// Any-hit walk of mesh m's 4-wide tree for the lanes with `own` (node-local ray r, padded by `pad`, limit tmax), by the
-// whole wave.  found = an accepted element of the lane's own ray (or ~0u); tie = the query has to be repeated exactly.
-__device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r, f3 drcp, float pad, float tmax, uint32_t *pool, uint32_t cap,
-                                          uint32_t &found, bool &tie, unsigned long long *fill = nullptr)
+// meta word of a ray slot: owner lane | x << 6 (closest: instance, any-hit: light of the batch) | padding << 14.  The padding
+// of the boxes rides as the float's upper 12 bits rounded UP (a larger padding is always safe).
+__device__ __forceinline__ uint32_t csMeta(uint32_t owner, uint32_t x, float pad)
+{
+  const uint32_t enc = (__float_as_uint(pad) + 0x7FFFFu) >> 19;
+  return owner | (x << 6) | (enc << 14);
+}
+__device__ __forceinline__ float csMetaPad(uint32_t meta) { return __uint_as_float((meta >> 14) << 19); }
+
+// Rounds until the pool is empty.  CLOSEST: keys / flags per owner lane; else: results per (light of the batch, owner lane).
+//
+// The pool is TWO stacks sharing the item array: node items grow up from its start, leaf items down from its end.  A round is
+// either a node round (every lane tests the four children of one node) or a leaf round (every lane tests the triangles of one
+// leaf): the wave never executes both bodies for a mixed set of items (in round 2's single-stack form every round paid for
+// both: ~390 vector instructions, of which a lane used half).  Leaf rounds go first once a wave's worth of leaves has
+// gathered (a hit shortens every walk of its ray), node rounds otherwise.
+template <bool CLOSEST>
+__device__ __forceinline__ void csRun(const DScene &sc, const CsLds &L, uint32_t &nNode, unsigned long long *fill)
 {
   const unsigned lane = __lane_id();
   const float INF = __builtin_inff();
-  const uint4 *wn = reinterpret_cast<const uint4 *>(m.wnodes), *tris = reinterpret_cast<const uint4 *>(m.wtris);
-  csSlot(pool, cap + lane) = 0;
-  csSlot(pool, cap + 64 + lane) = 0;
-  const unsigned long long mk = __ballot(own);
-  uint32_t n = (uint32_t) __popcll(mk);
-  if (own) csSlot(pool, (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))) = m.wrootWord | (lane << QA_CS_OWNER_SHIFT);
-  csWaveSync();
-  while (n) {
-    // With at most 16 items in the pool four lanes share an item: each tests ONE child of the node (or one triangle of the
-    // leaf), so an underfilled round costs a quarter of the arithmetic - and all items are taken every round.
-    const bool quad = n <= 16u;
-    const uint32_t take = quad ? n : (n < 64u ? n : 64u);
+  const uint4 *wn = sc.csNodes, *tris = sc.csTris;
+  const uint32_t cap = L.capItems;
+  uint32_t nLeaf = 0;
+  csWaveSync();   // the sweep's ray slots and root items
+#ifdef QA_STAMPS
+  const unsigned long long tRun = __builtin_readcyclecounter();
+#endif
+  while (nNode | nLeaf) {
+    const bool leafRound = nLeaf >= QA_CS_LEAF_ROUND || nNode == 0u;
+    const uint32_t have = leafRound ? nLeaf : nNode;
+    // With at most 16 items four lanes share an item: each tests ONE child of the node (or every fourth triangle of the
+    // leaf), so an underfilled round costs a quarter of the arithmetic - and all items are taken.
+    const bool quad = have <= 16u;
+    const uint32_t take = quad ? have : (have < 64u ? have : 64u);
     const uint32_t idx = quad ? (lane >> 2) : lane, sub = lane & 3u;
 #ifdef QA_STAMPS
-    if (fill && lane == 0) { fill[10] += quad ? 4u * take : take; fill[11] += 1; fill[12] += (take <= 16u) ? 1 : 0; }   /* lanes at work / rounds / rounds with <= 16 items */
+    if (fill && lane == 0) { fill[10] += quad ? 4u * take : take; fill[11] += 1; fill[12] += leafRound ? 1 : 0; }   /* lanes at work / rounds / leaf rounds */
 #endif
     const bool work = idx < take;
-    const uint32_t item = work ? csSlot(pool, n - take + idx) : 0u;
-    n -= take;
-    const uint32_t owner = (item >> QA_CS_OWNER_SHIFT) & 63u;
-    // the owner's ray, out of its registers
-    const f3 op = F3(__shfl(r.p.x, (int) owner), __shfl(r.p.y, (int) owner), __shfl(r.p.z, (int) owner));
-    const f3 od = F3(__shfl(r.d.x, (int) owner), __shfl(r.d.y, (int) owner), __shfl(r.d.z, (int) owner));
-    const f3 orc = F3(__shfl(drcp.x, (int) owner), __shfl(drcp.y, (int) owner), __shfl(drcp.z, (int) owner));
-    const float opad = __shfl(pad, (int) owner), hz = __shfl(tmax, (int) owner);
-    const bool live = work && csSlot(pool, cap + owner) == 0 && csSlot(pool, cap + 64 + owner) == 0;   // dropped once the ray is settled
-    const bool isLeaf = (item & QA_BVH_LEAF_BIT) != 0;
-    float k0 = INF, k1 = INF, k2 = INF, k3 = INF;
-    uint32_t w0 = QA_DONE, w1 = QA_DONE, w2 = QA_DONE, w3 = QA_DONE;
-    if (live && !isLeaf) {
-      const uint4 *nd = wn + 4 * (size_t) (item & QA_CS_INDEX_MASK);
-      const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
-      const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
-      const f3 drcp = orc;   // (the name QA_WIDE_CHILD uses)
-      if (quad) {
-        w0 = sub == 0 ? q3.x : sub == 1 ? q3.y : sub == 2 ? q3.z : q3.w;
-        QA_WIDE_CHILD(k0, w0, sub)
-      } else {
-        w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
-        QA_WIDE_CHILD(k0, w0, 0)
-        QA_WIDE_CHILD(k1, w1, 1)
-        QA_WIDE_CHILD(k2, w2, 2)
-        QA_WIDE_CHILD(k3, w3, 3)
+    // node items are popped from the top of their stack, leaf items from the low end of theirs (the most recent ones)
+    const uint32_t item = work ? L.items[leafRound ? cap - nLeaf + idx : nNode - take + idx] : 0u;
+    if (leafRound) nLeaf -= take;
+    else nNode -= take;
+    const uint32_t slot = (item >> QA_CS_SLOT_SHIFT) & QA_CS_SLOT_MASK;
+    const uint4 ra = L.rays[2 * slot], rb = L.rays[2 * slot + 1];
+    const f3 op = F3(asF(ra.x), asF(ra.y), asF(ra.z)), od = F3(asF(rb.x), asF(rb.y), asF(rb.z));
+    const uint32_t meta = rb.w, owner = meta & 63u, mx = (meta >> 6) & 0xFFu;
+    bool live;
+    float hz;
+    unsigned long long *key = csKeys(L) + owner;
+    if (CLOSEST) {
+      live = work && L.flags[owner] == 0;
+      hz = __uint_as_float((uint32_t) (*key >> 32));   // the distance the owner's path holds right now
+    } else {
+      live = work && L.res[mx * 64u + owner] == 0 && ((L.flags[owner] >> mx) & 1u) == 0;   // dropped once the query is settled
+      hz = asF(ra.w);
+    }
+    if (!leafRound) {
+      // ---- node round
+      const float opad = csMetaPad(meta);
+      // Reciprocal direction for the box tests of the library's own tree: one ulp off the division at most, which the boxes'
+      // padding covers many times over (1e-6 (|origin| + |mesh|) for the slab arithmetic, qa_widebvh.h); a zero component
+      // gives +-inf and a NaN slab that min / max ignore (the axis stays unbounded: conservative).
+      const f3 drcp = F3(__builtin_amdgcn_rcpf(od.x), __builtin_amdgcn_rcpf(od.y), __builtin_amdgcn_rcpf(od.z));
+      float k0 = INF, k1 = INF, k2 = INF, k3 = INF;
+      uint32_t w0 = QA_DONE, w1 = QA_DONE, w2 = QA_DONE, w3 = QA_DONE;
+      if (live && (item & QA_BVH_LEAF_BIT)) {
+        // (a mesh that is one leaf: its root goes over to the leaf stack)
+        if (!quad || sub == 0) { k3 = 0.f; w3 = item & ~(QA_CS_SLOT_MASK << QA_CS_SLOT_SHIFT); }
+      } else if (live) {
+        const uint4 *nd = wn + 4 * (size_t) (item & QA_CS_INDEX_MASK);
+        const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
+        const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
+        if (quad) {
+          w3 = sub == 0 ? q3.x : sub == 1 ? q3.y : sub == 2 ? q3.z : q3.w;   // (every item is taken every round while quad: no order to keep)
+          QA_WIDE_CHILD(k3, w3, sub)
+        } else {
+          w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
+          QA_WIDE_CHILD(k0, w0, 0)
+          QA_WIDE_CHILD(k1, w1, 1)
+          QA_WIDE_CHILD(k2, w2, 2)
+          QA_WIDE_CHILD(k3, w3, 3)
+          if (CLOSEST) {
+            // farthest first: a stack is popped from its top, so the nearest child of a node is looked at first.  (An any-hit
+            // query has no order to keep; sorting there was measured: it costs more than it finds.)
+            QA_WIDE_CE(k0, w0, k1, w1)
+            QA_WIDE_CE(k2, w2, k3, w3)
+            QA_WIDE_CE(k0, w0, k2, w2)
+            QA_WIDE_CE(k1, w1, k3, w3)
+            QA_WIDE_CE(k1, w1, k2, w2)
+          }
+        }
       }
-    }
-    // children the ray enters go back into the pool (any order will do for an any-hit query; looking at the nearest child
-    // first was measured: C3 749 -> 699, C5 1436 -> 1413 Msamples/s - the sort costs more than it finds)
+      // children the ray enters: inner ones onto the node stack, leaves onto the leaf stack (ballot + prefix, no atomics)
 #define QA_CS_PUSH(K, W)                                                                                     \
-    {                                                                                                        \
-      const bool p = K < INF;                                                                                \
-      const unsigned long long pm = __ballot(p);                                                             \
-      if (p) {                                                                                               \
-        const uint32_t at = n + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));                           \
-        if (at < cap) csSlot(pool, at) = W | (owner << QA_CS_OWNER_SHIFT);                                   \
-        else atomicOr(&csSlot(pool, cap + 64 + owner), 1u);   /* pool full: this ray is repeated exactly */  \
-      }                                                                                                      \
-      n += (uint32_t) __popcll(pm);                                                                          \
-      n = n < cap ? n : cap;                                                                                 \
-    }
-    QA_CS_PUSH(k0, w0)
-    if (!quad) {
-      QA_CS_PUSH(k1, w1)
-      QA_CS_PUSH(k2, w2)
+      {                                                                                                      \
+        const bool p = K < INF, pl = p && (W & QA_BVH_LEAF_BIT), pn = p && !(W & QA_BVH_LEAF_BIT);          \
+        const unsigned long long mn = __ballot(pn), ml = __ballot(pl);                                       \
+        const uint32_t room = cap - nNode - nLeaf, cn = (uint32_t) __popcll(mn), cl = (uint32_t) __popcll(ml); \
+        if (p) {                                                                                             \
+          const uint32_t at = pn ? (uint32_t) __popcll(mn & ((1ull << lane) - 1ull)) : cn + (uint32_t) __popcll(ml & ((1ull << lane) - 1ull)); \
+          if (at < room) L.items[pn ? nNode + at : cap - nLeaf - 1u - (at - cn)] = W | (slot << QA_CS_SLOT_SHIFT); \
+          else atomicOr(&L.flags[owner], CLOSEST ? 1u : (1u << mx));   /* pool full: this query is repeated exactly */ \
+        }                                                                                                    \
+        const uint32_t okn = cn < room ? cn : room, okl = (cn + cl <= room) ? cl : (room - okn);             \
+        nNode += okn;                                                                                        \
+        nLeaf += okl;                                                                                        \
+      }
       QA_CS_PUSH(k3, w3)
-    }
+      if (!quad) {
+        QA_CS_PUSH(k2, w2)
+        QA_CS_PUSH(k1, w1)
+        QA_CS_PUSH(k0, w0)
+      }
 #undef QA_CS_PUSH
-    if (live && isLeaf) {
+    } else if (live) {
+      // ---- leaf round: the leaf's triangles with the reference's arithmetic
       Ray oray;
       oray.p = op;
       oray.d = od;
@@ -128,313 +198,492 @@ __device__ __forceinline__ void csWalkAny(const DMesh &m, bool own, const Ray &r
         const uint4 *t = tris + 3 * (size_t) (first + i);
         const uint4 t2 = ldGlobal(t + 2);
         if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
-          csSlot(pool, cap + owner) = (t2.w >> 2) + 1u;   // several lanes may store for one owner: any accepted element will do
-          stop = true;
+          if (CLOSEST) {
+            const unsigned long long mine = ((unsigned long long) __float_as_uint(hzl) << 32) | (unsigned long long) ((mx << QA_CS_SLOT_SHIFT) | (t2.w >> 2));
+            const unsigned long long old = atomicMin(key, mine);
+            // another lane accepted this very distance meanwhile: the one situation in which the ORDER of the tests decides
+            if ((uint32_t) (old >> 32) == __float_as_uint(hzl) && old != mine) tl = true;
+          } else {
+            L.res[mx * 64u + owner] = ((slot << QA_CS_SLOT_SHIFT) | (first + i)) + 1u;   // several lanes may store for one query: any accepted triangle will do
+            stop = true;
+          }
         }
       }
-      if (tl) atomicOr(&csSlot(pool, cap + 64 + owner), 1u);
+      if (tl) atomicOr(&L.flags[owner], CLOSEST ? 1u : (1u << mx));
     }
     csWaveSync();
   }
-  found = own ? csSlot(pool, cap + lane) - 1u : ~0u;
-  tie = own && csSlot(pool, cap + 64 + lane) != 0;
-  csWaveSync();
+#ifdef QA_STAMPS
+  if (fill && lane == 0) fill[CLOSEST ? 3 : 6] += __builtin_readcyclecounter() - tRun;   /* the rounds alone */
+#endif
 }
 
-// TriObj::IntersectRay as an any-hit query against t_max, for the lanes with `go` (hitMesh<RES = false> of qa_kernel.h
-// with the 4-wide walk done by the whole wave).  Every lane of the wave calls this.
-__device__ __forceinline__ bool csAnyHitMesh(const DMesh &m, bool go, const Ray &ray, float tmax, uint32_t *pool, uint32_t cap,
-                                             uint32_t *stack, DCounters &cnt)
+// ---------------------------------------------------------------------------------------------
+// The exact walks: the reference's sequential scene-graph loop on the reference's trees, one lane per ray, out of line.
+// They decide WHO wins (distance, instance, element); the hit's details are computed by the common code below.
+// ---------------------------------------------------------------------------------------------
+struct CsWinner { float z; int k; uint32_t tri; };
+
+__device__ __forceinline__ Ray csRootRay(const qa_instance *inst, uint32_t rootIdentity, const Ray &world)
+{
+  if (!rootIdentity) return toNode(ldTable(inst), world);
+  Ray o;
+  o.p = world.p;
+  o.d = (world.p + world.d) - world.p;
+  return o;
+}
+__device__ __forceinline__ Ray csLocalRay(const qa_instance *inst, int k, const qa_instance &in, const Ray &r0)
+{
+  if (in.depth == 1) return toNode(in, r0);
+  int chain[QA_MAX_NODE_DEPTH];
+  int n = 0;
+  for (int a = k; a > 0 && n < QA_MAX_NODE_DEPTH; a = ldTable(inst + a).parent) chain[n++] = a;
+  Ray r = r0;
+  for (int q = n - 1; q >= 0; --q) r = toNode(ldTable(inst + chain[q]), r);
+  return r;
+}
+// TriObj::IntersectRay on the reference tree (hitMesh's STATS branch without the counters)
+__device__ __forceinline__ bool csExactMesh(const DMesh &m, const Ray &ray, float &hz, bool closest, uint32_t *stk, uint32_t &best)
+{
+  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+  const bool fastSlab = !__any(qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f);
+  float entry, meshExit;
+  if (fastSlab) boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+  else boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+  if (entry > hz || entry > meshExit) return false;   // Box::IntersectRay, src/core/box.cpp:94-128
+  if (m.num_faces == 0) return false;
+  DCounters none = {};
+  bool tie = false;
+  return walkBVH<false, false, true, 1>(reinterpret_cast<const uint4 *>(m.nodes), reinterpret_cast<const uint4 *>(m.tris), m.rootData, ray, drcp, fastSlab,
+                                        hz, closest, stk, none, best, tie);
+}
+
+__device__ __attribute__((noinline)) CsWinner csExactClosest(const qa_instance *inst, const DMesh *mesh, int num_inst, uint32_t rootIdentity, float px, float py,
+                                                             float pz, float dx, float dy, float dz)
+{
+  uint32_t stk[QA_CS_EXACT_STACK];
+  Ray world;
+  world.p = F3(px, py, pz);
+  world.d = F3(dx, dy, dz);
+  const Ray r0 = csRootRay(inst, rootIdentity, world);
+  CsWinner w;
+  w.z = QA_BIGFLOAT;
+  w.k = -1;
+  w.tri = 0;
+  for (int k = 1; k < num_inst; ++k) {
+    const qa_instance in = ldTable(inst + k);
+    if (in.obj_type == QA_OBJ_NONE) continue;
+    const Ray r = csLocalRay(inst, k, in, r0);
+    Hit h;
+    h.z = w.z;
+    h.node = -1;
+    if (in.obj_type == QA_OBJ_SPHERE) {
+      if (hitSphere(r, h, k, false)) { w.z = h.z; w.k = k; }
+    } else if (in.obj_type == QA_OBJ_PLANE) {
+      if (hitPlane(r, h, k, false)) { w.z = h.z; w.k = k; }
+    } else {
+      const DMesh m = ldTable(mesh + in.mesh);
+      uint32_t best = 0;
+      if (csExactMesh(m, r, h.z, true, stk, best)) { w.z = h.z; w.k = k; w.tri = best; }
+    }
+  }
+  return w;
+}
+
+__device__ __attribute__((noinline)) bool csExactShadow(const qa_instance *inst, const DMesh *mesh, int num_inst, uint32_t rootIdentity, float px, float py, float pz,
+                                                        float dx, float dy, float dz, float tmax)
+{
+  uint32_t stk[QA_CS_EXACT_STACK];
+  Ray world;
+  world.p = F3(px, py, pz);
+  world.d = F3(dx, dy, dz);
+  const Ray r0 = csRootRay(inst, rootIdentity, world);
+  for (int k = 1; k < num_inst; ++k) {
+    const qa_instance in = ldTable(inst + k);
+    if (in.obj_type == QA_OBJ_NONE) continue;
+    const Ray r = csLocalRay(inst, k, in, r0);
+    Hit h;
+    h.z = tmax;
+    h.node = -1;
+    bool hit;
+    if (in.obj_type == QA_OBJ_SPHERE) hit = hitSphere(r, h, k, false);
+    else if (in.obj_type == QA_OBJ_PLANE) hit = hitPlane(r, h, k, false);
+    else {
+      const DMesh m = ldTable(mesh + in.mesh);
+      uint32_t best = 0;
+      hit = csExactMesh(m, r, h.z, false, stk, best);
+    }
+    if (hit) return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep helpers
+// ---------------------------------------------------------------------------------------------
+// The bounding-box gate of TriObj::IntersectRay (src/objects/objects.cpp:310-322, Box::IntersectRay src/core/box.cpp:94-128)
+template <class M>
+__device__ __forceinline__ bool csGate(const M &m, const Ray &ray, float limit)
 {
   const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
   const bool nearZero = qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f;
-  if (go) {
-    float entry, meshExit;
-    if (nearZero) boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
-    else boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
-    if (entry > tmax || entry > meshExit) go = false;   // Box::IntersectRay, src/core/box.cpp:94-128
-  }
-  if (m.num_faces == 0) go = false;
-  const bool coop = go && m.useWide && insideCancelReach(m, ray.p);
-  bool redo = go && !coop, hasHit = false;
-  if (__any(coop)) {
-    const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
-    const float pad = m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
-    uint32_t found;
-    bool tie;
-    QA_T(tW)
-    csWalkAny(m, coop, ray, drcp, pad, tmax, pool, cap, found, tie, QA_FILL(cnt));
-    QA_TACC(cnt.sl[6], tW)
-    if (coop) {
-      redo = tie;
-      if (found != ~0u && !tie) {
-        // the reference reports "occluded" iff it reaches an accepted triangle: this one's leaf must pass its strict test
-        // against the ray's fixed t_max; if it does not, only the sequential walk can tell
-        const uint32_t leaf = ldGlobal(reinterpret_cast<const uint4 *>(m.shade) + 3 * (size_t) found + 2).w;   // DTriShade::pad
-        if (refReaches<true>(reinterpret_cast<const uint4 *>(m.nodes), leaf, ray, drcp, !nearZero, tmax)) hasHit = true;
-        else redo = true;
-      }
-    }
-  }
-  if (redo) {
-    float hz = tmax;
-    uint32_t bestTri = 0;
-    bool tie = false;
-    const bool fastSlab = !__any(nearZero);
-    hasHit = walkBVH<false, false, true>(reinterpret_cast<const uint4 *>(m.nodes), reinterpret_cast<const uint4 *>(m.tris), m.rootData, ray, drcp,
-                                         fastSlab, hz, false, stack, cnt, bestTri, tie);
-  }
-  return hasHit;
+  float entry, meshExit;
+  if (nearZero) boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+  else boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
+  return !(entry > limit || entry > meshExit) && m.num_faces != 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Closest-hit walks by the whole wave.  (A twin of csWalkAny on purpose: folded into one template the textured kernel runs
-// 4 % slower - C3 748 -> 719 Msamples/s - for the same instructions in another order; session3_experiments.txt, item 18.)  Same pool; behind it 64 result keys (distance bits << 32 | element: one
-// ds_min_u64 per accepted triangle, and the distance half is what every lane prunes and accepts against, so a hit found by
-// one lane shortens the work of all lanes on that ray at once) and 64 flag words.  A triangle that passes the inside test at
-// exactly the distance held - whether that distance was there before the test or arrived from another lane at the same
-// moment (the atomic's return value) - raises the flag: the one situation in which the ORDER of the tests decides
-// (hitMesh then repeats the query in the reference's order, as after a tie of the sequential 4-wide walk).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long *csKey(uint32_t *pool, uint32_t cap, uint32_t owner)
-{
-  // 64 keys = two pool rows of 64 words; key o sits in row o / 32
-  return reinterpret_cast<unsigned long long *>(&csSlot(pool, cap + (owner >> 5) * 64u)) + (owner & 31u);
-}
-
-__device__ __forceinline__ void csWalkClosest(const DMesh &m, bool own, const Ray &r, f3 drcp, float pad, float limit, uint32_t *pool, uint32_t cap,
-                                              float &hz, uint32_t &found, bool &tie, unsigned long long *fill = nullptr)
+// The any-hit results of one run of the pool: a recorded triangle counts when the reference's walk reaches it - its leaf in
+// the reference tree passes the strict box test against the ray's fixed t_max (exact for an any-hit query: the reference
+// reports "occluded" iff it reaches an accepted triangle); if it does not, only the sequential walk can tell.
+__device__ __forceinline__ void csSettleShadows(const DScene &sc, const CsLds &L, uint32_t nb, uint32_t &occl, uint32_t &redo)
 {
   const unsigned lane = __lane_id();
-  const float INF = __builtin_inff();
-  const uint4 *wn = reinterpret_cast<const uint4 *>(m.wnodes), *tris = reinterpret_cast<const uint4 *>(m.wtris);
-  *csKey(pool, cap, lane) = ((unsigned long long) __float_as_uint(limit) << 32) | 0xFFFFFFFFull;
-  csSlot(pool, cap + 128 + lane) = 0;
-  const unsigned long long mk = __ballot(own);
-  uint32_t n = (uint32_t) __popcll(mk);
-  if (own) csSlot(pool, (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))) = m.wrootWord | (lane << QA_CS_OWNER_SHIFT);
-  csWaveSync();
-  while (n) {
-    const bool quad = n <= 16u;   // four lanes per item, one child / triangle each (csWalkAny)
-    const uint32_t take = quad ? n : (n < 64u ? n : 64u);
-    const uint32_t idx = quad ? (lane >> 2) : lane, sub = lane & 3u;
-#ifdef QA_STAMPS
-    if (fill && lane == 0) { fill[10] += quad ? 4u * take : take; fill[11] += 1; fill[12] += (take <= 16u) ? 1 : 0; }
-#endif
-    const bool work = idx < take;
-    const uint32_t item = work ? csSlot(pool, n - take + idx) : 0u;
-    n -= take;
-    const uint32_t owner = (item >> QA_CS_OWNER_SHIFT) & 63u;
-    const f3 op = F3(__shfl(r.p.x, (int) owner), __shfl(r.p.y, (int) owner), __shfl(r.p.z, (int) owner));
-    const f3 od = F3(__shfl(r.d.x, (int) owner), __shfl(r.d.y, (int) owner), __shfl(r.d.z, (int) owner));
-    const f3 orc = F3(__shfl(drcp.x, (int) owner), __shfl(drcp.y, (int) owner), __shfl(drcp.z, (int) owner));
-    const float opad = __shfl(pad, (int) owner);
-    unsigned long long *key = csKey(pool, cap, owner);
-    const bool live = work && csSlot(pool, cap + 128 + owner) == 0;
-    const float hzNow = __uint_as_float((uint32_t) (*key >> 32));   // the distance the owner's ray holds right now
-    const bool isLeaf = (item & QA_BVH_LEAF_BIT) != 0;
-    float k0 = INF, k1 = INF, k2 = INF, k3 = INF;
-    uint32_t w0 = QA_DONE, w1 = QA_DONE, w2 = QA_DONE, w3 = QA_DONE;
-    if (live && !isLeaf) {
-      const uint4 *nd = wn + 4 * (size_t) (item & QA_CS_INDEX_MASK);
-      const uint4 q0 = ldGlobal(nd), q1 = ldGlobal(nd + 1), q2 = ldGlobal(nd + 2), q3 = ldGlobal(nd + 3);
-      const f3 pLo = op + F3(opad, opad, opad), pHi = op - F3(opad, opad, opad);
-      const f3 drcp = orc;
-      const float hz = hzNow;   // (the names QA_WIDE_CHILD uses)
-      if (quad) {
-        w3 = sub == 0 ? q3.x : sub == 1 ? q3.y : sub == 2 ? q3.z : q3.w;   // (every item is taken every round while quad: no order to keep)
-        QA_WIDE_CHILD(k3, w3, sub)
-      } else {
-        w0 = q3.x; w1 = q3.y; w2 = q3.z; w3 = q3.w;
-        QA_WIDE_CHILD(k0, w0, 0)
-        QA_WIDE_CHILD(k1, w1, 1)
-        QA_WIDE_CHILD(k2, w2, 2)
-        QA_WIDE_CHILD(k3, w3, 3)
-        // farthest first: the pool is popped from its top, so the nearest child of a node is looked at first
-        QA_WIDE_CE(k0, w0, k1, w1)
-        QA_WIDE_CE(k2, w2, k3, w3)
-        QA_WIDE_CE(k0, w0, k2, w2)
-        QA_WIDE_CE(k1, w1, k3, w3)
-        QA_WIDE_CE(k1, w1, k2, w2)
+  redo |= L.flags[lane];
+  for (uint32_t jj = 0; jj < nb; ++jj) {
+    const uint32_t f = L.res[jj * 64u + lane];
+    if (!__any(f != 0)) continue;
+    if (f != 0 && !((occl | redo) >> jj & 1u)) {
+      const uint32_t slot = ((f - 1u) >> QA_CS_SLOT_SHIFT) & QA_CS_SLOT_MASK, gtri = (f - 1u) & QA_CS_INDEX_MASK;
+      const uint4 ra = L.rays[2 * slot], rb = L.rays[2 * slot + 1];
+      Ray r;
+      r.p = F3(asF(ra.x), asF(ra.y), asF(ra.z));
+      r.d = F3(asF(rb.x), asF(rb.y), asF(rb.z));
+      const uint4 b0 = ldGlobal(sc.csLeafBox + 2 * (size_t) gtri), b1 = ldGlobal(sc.csLeafBox + 2 * (size_t) gtri + 1);
+      bool reached = asF(b1.z) != 0.f;   // the leaf is the root: entered unconditionally
+      if (!reached) {
+        const f3 drcp = F3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+        const bool nearZero = qabs(r.d.x) < 1e-7f || qabs(r.d.y) < 1e-7f || qabs(r.d.z) < 1e-7f;
+        const f3 bmin = F3(asF(b0.x), asF(b0.y), asF(b0.z)), bmax = F3(asF(b0.w), asF(b1.x), asF(b1.y));
+        float entry, exit_;
+        if (nearZero) boxEntryExit(r, drcp, bmin, bmax, entry, exit_);
+        else boxEntryExitFast(r, drcp, bmin, bmax, entry, exit_);
+        reached = entry < asF(ra.w) && entry < exit_;
       }
+      if (reached) occl |= 1u << jj;
+      else redo |= 1u << jj;
     }
-#define QA_CS_PUSH(K, W)                                                                                     \
-    {                                                                                                        \
-      const bool p = K < INF;                                                                                \
-      const unsigned long long pm = __ballot(p);                                                             \
-      if (p) {                                                                                               \
-        const uint32_t at = n + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));                           \
-        if (at < cap) csSlot(pool, at) = W | (owner << QA_CS_OWNER_SHIFT);                                   \
-        else atomicOr(&csSlot(pool, cap + 128 + owner), 1u);                                                 \
-      }                                                                                                      \
-      n += (uint32_t) __popcll(pm);                                                                          \
-      n = n < cap ? n : cap;                                                                                 \
-    }
-    QA_CS_PUSH(k3, w3)
-    if (!quad) {
-      QA_CS_PUSH(k2, w2)
-      QA_CS_PUSH(k1, w1)
-      QA_CS_PUSH(k0, w0)
-    }
-#undef QA_CS_PUSH
-    if (live && isLeaf) {
-      Ray oray;
-      oray.p = op;
-      oray.d = od;
-      const uint32_t count = ((item >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
-      const uint32_t first = item & QA_CS_INDEX_MASK;
-      const uint32_t i0 = quad ? sub : 0u, di = quad ? 4u : 1u;
-      float hzl = hzNow;
-      bool tl = false;
-      for (uint32_t i = i0; i < count; i += di) {
-        const uint4 *t = tris + 3 * (size_t) (first + i);
-        const uint4 t2 = ldGlobal(t + 2);
-        if (hitTriangleZTie<true>(ldGlobal(t), ldGlobal(t + 1), t2, oray, hzl, tl)) {
-          const unsigned long long mine = ((unsigned long long) __float_as_uint(hzl) << 32) | (unsigned long long) (t2.w >> 2);
-          const unsigned long long old = atomicMin(key, mine);
-          if ((uint32_t) (old >> 32) == __float_as_uint(hzl) && old != mine) tl = true;   // another lane accepted this very distance meanwhile
-        }
-      }
-      if (tl) atomicOr(&csSlot(pool, cap + 128 + owner), 1u);
-    }
-    csWaveSync();
   }
-  const unsigned long long k = *csKey(pool, cap, lane);
-  found = own ? (uint32_t) k : ~0u;            // 0xFFFFFFFF: nothing accepted
-  hz = __uint_as_float((uint32_t) (k >> 32));
-  tie = own && csSlot(pool, cap + 128 + lane) != 0;
-  csWaveSync();
+  csWaveSync();   // results and ray slots have been read: the next run may overwrite them
+  for (uint32_t jj = 0; jj < nb; ++jj) L.res[jj * 64u + lane] = 0;
+  L.flags[lane] = 0;
 }
 
-// hitMesh<RES = false>(closest = true) of qa_kernel.h with the 4-wide walk done by the whole wave; `go`: this lane has a ray.
-__device__ __forceinline__ bool csHitMeshClosest(const DMesh &m, bool go, const Ray &ray, Hit &h, int k, uint32_t *pool, uint32_t cap,
-                                                 uint32_t *stack, DCounters &cnt, TriPick &pick)
+// Node::ToNodeCoords through the levels of a flat instance record (toNode / localRay of qa_kernel.h: the same operations)
+__device__ __forceinline__ Ray csToNode(const float *itm, const float *pos, const Ray &r)
 {
-  const f3 drcp = F3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-  const bool nearZero = qabs(ray.d.x) < 1e-7f || qabs(ray.d.y) < 1e-7f || qabs(ray.d.z) < 1e-7f;
-  if (go) {
-    float entry, meshExit;
-    if (nearZero) boxEntryExit(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
-    else boxEntryExitFast(ray, drcp, ld3(m.bmin), ld3(m.bmax), entry, meshExit);
-    if (entry > h.z || entry > meshExit) go = false;
+  const f3 o = ld3(pos);
+  Ray out;
+  out.p = mulMV(itm, r.p - o);
+  out.d = mulMV(itm, (r.p + r.d) - o) - out.p;
+  return out;
+}
+__device__ __forceinline__ Ray csLocal(const CsInst &ci, const Ray &r0)
+{
+  Ray r = csToNode(ci.itmA, ci.posA, r0);
+  if (ci.depth == 2) r = csToNode(ci.itmB, ci.posB, r);
+  return r;
+}
+// The same in a sweep over the nodes in pre-order: the children of a group follow each other, so the group's own ray is kept
+// from one child to the next (five walls in one group: the level-A transform once instead of five times; same operations)
+__device__ __forceinline__ Ray csLocalSweep(const CsInst &ci, const Ray &r0, GroupRay &g)
+{
+  if (ci.depth != 2) return csToNode(ci.itmA, ci.posA, r0);
+  if (ci.parent != g.node) {
+    g.ray = csToNode(ci.itmA, ci.posA, r0);
+    g.node = ci.parent;
   }
-  if (m.num_faces == 0) go = false;
-  const uint4 *nodes = reinterpret_cast<const uint4 *>(m.nodes), *tris = reinterpret_cast<const uint4 *>(m.tris), *shade = reinterpret_cast<const uint4 *>(m.shade);
-  const float hz0 = h.z;
-  const bool coop = go && m.useWide && insideCancelReach(m, ray.p);
-  bool redo = go && !coop, hasHit = false;
-  uint32_t bestTri = 0;
-  if (__any(coop)) {
-    const float oMax = qmax(qmax(qabs(ray.p.x), qabs(ray.p.y)), qabs(ray.p.z));
-    const float pad = m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
-    float hz;
-    uint32_t found;
-    bool tie;
-    QA_T(tW)
-    csWalkClosest(m, coop, ray, drcp, pad, hz0, pool, cap, hz, found, tie, QA_FILL(cnt));
-    QA_TACC(cnt.sl[3], tW)
-    if (coop) {
-      redo = tie;
-      if (found != 0xFFFFFFFFu && !tie) {
-        const uint32_t leaf = ldGlobal(shade + 3 * (size_t) found + 2).w;   // DTriShade::pad
-        if (refReaches<true>(nodes, leaf, ray, drcp, !nearZero, hz)) {
-          hasHit = true;
-          bestTri = found;
-          h.z = hz;
-        } else redo = true;
-      }
-    }
+  return csToNode(ci.itmB, ci.posB, g.ray);
+}
+// Node::FromNodeCoords at every level from the hit node up to and including the (identity) root (src/core/node.cpp:127-139)
+__device__ __forceinline__ void csToWorld(const CsInst &ci, f3 &p, f3 &N)
+{
+  if (ci.depth == 2) {
+    p = mulMV(ci.tmB, p) + ld3(ci.posB);
+    N = normalize(mulTMV(ci.itmB, N));
   }
-  if (redo) {
-    h.z = hz0;
-    bool tie = false;
-    const bool fastSlab = !__any(nearZero);
-    hasHit = walkBVH<false, false, true>(nodes, tris, m.rootData, ray, drcp, fastSlab, h.z, true, stack, cnt, bestTri, tie);
+  p = mulMV(ci.tmA, p) + ld3(ci.posA);
+  N = normalize(mulTMV(ci.itmA, N));
+  N = normalize(N);   // identity root: p unchanged, the normal is still re-normalised
+}
+
+// A lane with `coop` takes ray slot nSlots + (its rank among the entering lanes) and pushes the mesh's root there.
+__device__ __forceinline__ void csEnter(const CsLds &L, unsigned long long mk, bool coop, const Ray &r, float limit, uint32_t x, float pad, uint32_t rootWord, uint32_t n,
+                                        uint32_t nSlots)
+{
+  const unsigned lane = __lane_id();
+  if (coop) {
+    const uint32_t at = (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
+    const uint32_t slot = nSlots + at;
+    L.rays[2 * slot] = make_uint4(__float_as_uint(r.p.x), __float_as_uint(r.p.y), __float_as_uint(r.p.z), __float_as_uint(limit));
+    L.rays[2 * slot + 1] = make_uint4(__float_as_uint(r.d.x), __float_as_uint(r.d.y), __float_as_uint(r.d.z), csMeta(lane, x, pad));
+    L.items[n + at] = rootWord | (slot << QA_CS_SLOT_SHIFT);
   }
-  if (hasHit) {
-    float ba = 0, bb = 0;
-    {
-      const uint4 *t = tris + 3 * (size_t) bestTri;
-      triangleDetails(ldGlobal(t), ldGlobal(t + 1), ldGlobal(t + 2), ray, h, ba, bb);
-    }
-    // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
-    const uint4 *s = shade + 3 * (size_t) bestTri;
-    const uint4 s0 = ldGlobal(s), s1 = ldGlobal(s + 1), s2 = ldGlobal(s + 2);
-    const float bc = 1.f - ba - bb;
-    const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)), n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));
-    h.N = (n0 * ba + n1 * bb) + n2 * bc;
-    h.mtlID = (int) s2.y;
-    h.node = k;
-    pick.tri = bestTri;
-    pick.a = ba;
-    pick.b = bb;
-  }
-  return hasHit;
+}
+template <class M>
+__device__ __forceinline__ float csPad(const M &m, f3 o)
+{
+  const float oMax = qmax(qmax(qabs(o.x), qabs(o.y)), qabs(o.z));
+  return m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
 }
 
 // Scene::TraceNodeNormal (traceClosest of qa_kernel.h) for the lanes with `act`; every lane of the wave calls this.
+// The x / y differential directions of the path's current ray (DiffRay, src/core/ray.h:55-63): camera rays - the pixel sample
+// shifted by DiffRay::dx / dy (renderer.cpp:314-317; the ray's origin is the lens point) - secondary rays - both equal the
+// ray's direction.  A function of what the path keeps anyway, so it is evaluated when a textured hit needs it.
+__device__ __forceinline__ f3 csTexPos(const DScene &sc, uint32_t pxy, int sidx)
+{
+  return F3(sc.halton[2 * sidx], sc.halton[2 * sidx + 1], 0.f) + F3((float) (pxy & 0xFFFFu), (float) (pxy >> 16), 0.f);
+}
+__device__ __forceinline__ RayDiff csRayDiff(const DScene &sc, const Ray &world, bool primary, uint32_t pxy, int sidx)
+{
+  RayDiff wd;
+  wd.dx = wd.dy = world.d;
+  if (primary) {
+    const f3 texpos = csTexPos(sc, pxy, sidx);
+    const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
+    const f3 xpt = (A + U * (texpos.x + QA_DX)) + V * texpos.y;
+    const f3 ypt = (A + U * texpos.x) + V * (texpos.y + QA_DX);
+    wd.dx = normalize(xpt - world.p);
+    wd.dy = normalize(ypt - world.p);
+  }
+  return wd;
+}
+
 template <bool TEX>
-__device__ __forceinline__ bool csTraceClosest(const DScene &sc, bool act, const Ray &world, const RayDiff &wd, Hit &h, TexHit &th, uint32_t *pool,
-                                               uint32_t cap, uint32_t *stack, DCounters &cnt)
+__device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L, bool act, const Ray &world, bool primary, uint32_t pxy, int sidx, Hit &h, TexHit &th,
+                                               DCounters &cnt)
 {
   if (!__any(act)) return false;
-  if (act) cnt.casts_normal++;
+  const unsigned lane = __lane_id();
+  cnt.casts_normal += (unsigned long long) __popcll(__ballot(act));   // (wave-uniform tallies: no registers per lane)
   const Ray r0 = rootRay<false>(sc, world);
+  // ---- ONE sweep over the instances in the reference's order: spheres and planes on the spot (distance and node only; the
+  // winner's details below), meshes into the pool; the pool runs when it is full, and at the end.
+  float bestZ = QA_BIGFLOAT;   // closest sphere / plane so far
+  int bestK = -1;
+  f3 spP = F3(0, 0, 0), spN = F3(0, 0, 0);   // !TEX: that hit in node space (TEX: its details wait for the winner, below)
+  bool spFront = true;
+  bool exact = false;          // this lane's query goes to the exact walk
+  csKeys(L)[lane] = ((unsigned long long) __float_as_uint(QA_BIGFLOAT) << 32) | 0xFFFFFFFFull;
+  L.flags[lane] = 0;
+  uint32_t n = 0, nSlots = 0;
   GroupRay grp;
   grp.node = -1;
   grp.ray = r0;
-  bool any = false;
-  for (int k = 1; k < sc.num_inst; ++k) {
-    const qa_instance in = instAt<false>(sc, k);
-    const int type = in.obj_type;
-    if (type == QA_OBJ_NONE) continue;
-    // (the node-local differential directions are only needed by an object that is hit: they are built then, by the
-    // same chain of operations localRayDiff performs for the central ray, instead of for every node of every query)
-    const Ray r = localRayInGroup<false>(sc, k, r0, grp);
-    bool hit = false;
-    if (type == QA_OBJ_SPHERE) {
-      if (act) hit = hitSphere(r, h, k, true);
-      if (TEX && hit) {
-        Ray r2;
-        RayDiff rd;
-        localRayDiff<false>(sc, k, world, wd, r2, rd);
-        texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+  QA_T(tSweep)
+  for (int k = 1; k <= sc.num_inst; ++k) {
+    const bool last = k == sc.num_inst;
+    bool coop = false;
+    Ray r;
+    r.p = r.d = F3(0, 0, 0);
+    float pad = 0.f;
+    uint32_t rootWord = 0;
+    if (!last) {
+      const CsInst ci = ldTable(sc.csInst + k);
+      const int type = ci.type;
+      if (type == QA_OBJ_NONE) continue;
+      r = csLocalSweep(ci, r0, grp);
+      if (type != QA_OBJ_MESH) {
+        Hit hh;
+        hh.z = bestZ;
+        hh.node = -1;
+        hh.p = hh.N = F3(0, 0, 0);
+        hh.front = true;
+        const bool hit = act && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, !TEX) : hitPlane(r, hh, k, !TEX));
+        if (hit) {
+          bestZ = hh.z;
+          bestK = k;
+          if (!TEX) {
+            spP = hh.p;
+            spN = hh.N;
+            spFront = hh.front;
+          }
+        }
+        continue;
       }
-    } else if (type == QA_OBJ_PLANE) {
-      if (act) hit = hitPlane(r, h, k, true);
-      if (TEX && hit) {
-        Ray r2;
-        RayDiff rd;
-        localRayDiff<false>(sc, k, world, wd, r2, rd);
-        texPlane(r.p, rd.dx, rd.dy, h.p, th);
+      // (gate against the spheres and planes met so far: any limit not below the final answer is safe, and a triangle at
+      // exactly the distance held raises the flag whatever the gate saw)
+      const bool go = act && csGate(ci, r, bestZ);
+      coop = go && ci.useWide && insideCancelReach(ci, r.p);
+      exact = exact || (go && !coop);
+      pad = csPad(ci, r.p);
+      rootWord = ci.csRootWord;
+    }
+    const unsigned long long mk = __ballot(coop);
+    const uint32_t c = (uint32_t) __popcll(mk);
+    if (last ? n != 0 : (c != 0 && (nSlots + c > L.slots || n + c > L.capItems))) {
+      // the walks prune against what the spheres and planes have already settled
+      if (bestK >= 0) {
+        unsigned long long *key = csKeys(L) + lane;
+        const unsigned long long mine = ((unsigned long long) __float_as_uint(bestZ) << 32) | 0xFFFFFFFFull, old = *key;
+        if ((uint32_t) (old >> 32) == __float_as_uint(bestZ) && old != mine) L.flags[lane] = 1;   // a triangle at exactly that distance: order decides
+        if (mine < old) *key = mine;
       }
-    } else {
-      const DMesh m = meshAt<false>(sc, in.mesh);
-      TriPick pick;
-      hit = csHitMeshClosest(m, act, r, h, k, pool, cap, stack, cnt, pick);
-      if (TEX && hit && m.hasVT) {
-        Ray r2;
-        RayDiff rd;
-        localRayDiff<false>(sc, k, world, wd, r2, rd);
-        const uint4 *t = reinterpret_cast<const uint4 *>(m.tris) + 3 * (size_t) pick.tri;
-        texTriangle(ldGlobal(t), ldGlobal(t + 1), ldGlobal(t + 2), m.vt + 6 * (size_t) pick.tri, r.p, rd.dx, rd.dy, pick.a, pick.b, th);
+      csRun<true>(sc, L, n, QA_FILL(cnt));
+      nSlots = 0;
+    }
+    if (c) {
+      csEnter(L, mk, coop, r, 0.f, (uint32_t) k, pad, rootWord, n, nSlots);
+      n += c;
+      nSlots += c;
+    }
+  }
+  QA_TACC(cnt.sl[13], tSweep)
+  QA_T(tDet)
+  uint32_t elem;
+  float meshZ;
+  {
+    const unsigned long long key = csKeys(L)[lane];
+    exact = exact || L.flags[lane] != 0;
+    elem = (uint32_t) key;
+    meshZ = __uint_as_float((uint32_t) (key >> 32));
+    // a sphere or plane met after the last run of the pool
+    if (elem != 0xFFFFFFFFu && bestK >= 0) {
+      if (meshZ == bestZ) exact = true;
+      else if (bestZ < meshZ) elem = 0xFFFFFFFFu;
+    }
+    csWaveSync();   // the keys have been read: the region may be reused
+  }
+  // ---- who wins
+  h.z = QA_BIGFLOAT;
+  h.node = -1;
+  h.mtlID = 0;
+  h.front = true;
+  h.p = h.N = F3(0, 0, 0);
+  th.uvw = F3(0.5f, 0.5f, 0.5f);   // HitInfo::Init (src/core/hitinfo.cpp:31-42)
+  th.duvw0 = th.duvw1 = F3(0, 0, 0);
+  th.hasTexture = false;
+  int winK = bestK;
+  float z = bestZ;
+  uint32_t tri = 0;
+  bool check = false;   // a mesh hit from the pool: the order check below
+  bool isMesh = false;
+  if (act && !exact && elem != 0xFFFFFFFFu) {
+    winK = (int) ((elem >> QA_CS_SLOT_SHIFT) & 0xFFu);
+    tri = elem & QA_CS_INDEX_MASK;
+    z = meshZ;
+    check = true;
+    isMesh = true;
+  }
+  bool found = false;
+  if (!TEX) {
+    // a sphere or plane won: its node-space hit goes to world space now - once, every lane through ITS node's record (the
+    // rays of a wave hit different walls: a loop over the nodes would repeat this for each of them)
+    if (act && !exact && !isMesh && bestK >= 0) {
+      csToWorld(sc.csInst[bestK], spP, spN);
+      h.z = bestZ;
+      h.p = spP;
+      h.N = spN;
+      h.front = spFront;
+      h.node = bestK;
+      h.mtlID = 0;
+      found = true;
+    }
+  }
+  // ---- details of the other winners, per instance (wave-uniform k: the tables are scalar loads).  Two rounds at most: a lane
+  // whose pool answer fails the order check repeats its query exactly and is then finished like the others.
+  bool pending = act && !exact && winK >= 0 && !found;
+  for (int round = 0; round < 2; ++round) {
+    if (round == 1) {
+      if (!__any(exact)) break;
+#ifdef QA_STAMPS
+      if (lane == 0) cnt.sl[15] += (unsigned long long) __popcll(__ballot(exact));
+#endif
+      if (exact) {
+        const CsWinner w = csExactClosest(sc.inst, sc.mesh, sc.num_inst, sc.rootIdentity, world.p.x, world.p.y, world.p.z, world.d.x, world.d.y, world.d.z);
+        winK = w.k;
+        z = w.z;
+        tri = w.tri;
+        check = false;
+        found = false;
+        pending = act && winK >= 0;
+      }
+      exact = false;
+    }
+    if (!__any(pending)) continue;
+    RayDiff wd;
+    wd.dx = wd.dy = world.d;
+    if (TEX) wd = csRayDiff(sc, world, primary, pxy, sidx);
+    for (int k = 1; k < sc.num_inst; ++k) {
+      const bool mine = pending && winK == k;
+      if (!__any(mine)) continue;
+      const CsInst ci = ldTable(sc.csInst + k);
+      const Ray r = csLocal(ci, r0);
+      bool ok = mine;
+      if (ci.type == QA_OBJ_SPHERE) {
+        if (mine) {
+          // Sphere::IntersectRay's accepted hit (hitSphere, closest = true) at the root found above
+          const f3 p = r.p + r.d * z;
+          const f3 N = normalize(p);
+          h.p = p;
+          h.N = N;
+          h.front = (dot(N, r.d) <= 0);
+          h.mtlID = 0;
+          if (TEX) {
+            Ray r2;
+            RayDiff rd;
+            localRayDiff<false>(sc, k, world, wd, r2, rd);
+            texSphere(r.p, rd.dx, rd.dy, h.p, h.N, th);
+          }
+        }
+      } else if (ci.type == QA_OBJ_PLANE) {
+        if (mine) {
+          h.p = r.p + r.d * z;
+          h.N = F3(0, 0, 1);
+          h.front = (dot(h.N, r.d) <= 0);
+          h.mtlID = 0;
+          if (TEX) {
+            Ray r2;
+            RayDiff rd;
+            localRayDiff<false>(sc, k, world, wd, r2, rd);
+            texPlane(r.p, rd.dx, rd.dy, h.p, th);
+          }
+        }
+      } else {
+        const DMesh m = meshAt<false>(sc, (int) ci.mesh);
+        const uint4 *nodes = reinterpret_cast<const uint4 *>(m.nodes), *tris = reinterpret_cast<const uint4 *>(m.tris), *shade = reinterpret_cast<const uint4 *>(m.shade);
+        if (mine) {
+          const uint4 *s = shade + 3 * (size_t) tri;
+          const uint4 s0 = ldGlobal(s), s1 = ldGlobal(s + 1), s2 = ldGlobal(s + 2);
+          if (check) {
+            // would the reference's walk have reached this triangle?  (refReaches: its leaf must pass the strict box test at the
+            // found distance; the reference's running distance is never smaller.)  If not, only the sequential walk can tell.
+            const f3 drcp = F3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+            const bool nearZero = qabs(r.d.x) < 1e-7f || qabs(r.d.y) < 1e-7f || qabs(r.d.z) < 1e-7f;
+            if (!refReaches<true>(nodes, s2.w /* DTriShade::pad */, r, drcp, !nearZero, z)) { ok = false; exact = true; }
+          }
+          if (ok) {
+            float ba = 0, bb = 0;
+            h.z = z;
+            const uint4 *t = tris + 3 * (size_t) tri;
+            const uint4 t0 = ldGlobal(t), t1 = ldGlobal(t + 1), t2 = ldGlobal(t + 2);
+            triangleDetails(t0, t1, t2, r, h, ba, bb);
+            // shading normal: TriMesh::GetNormal (src/mesh/TriMesh.h:196-204), left un-normalised
+            const float bc = 1.f - ba - bb;
+            const f3 n0 = F3(asF(s0.x), asF(s0.y), asF(s0.z)), n1 = F3(asF(s0.w), asF(s1.x), asF(s1.y)), n2 = F3(asF(s1.z), asF(s1.w), asF(s2.x));
+            h.N = (n0 * ba + n1 * bb) + n2 * bc;
+            h.mtlID = (int) s2.y;
+            if (TEX && m.hasVT) {
+              Ray r2;
+              RayDiff rd;
+              localRayDiff<false>(sc, k, world, wd, r2, rd);
+              texTriangle(t0, t1, t2, m.vt + 6 * (size_t) tri, r.p, rd.dx, rd.dy, ba, bb, th);
+            }
+          }
+        }
+      }
+      if (ok) {
+        h.z = z;
+        h.node = k;
+        found = true;
+        csToWorld(ci, h.p, h.N);
       }
     }
-    any |= hit;
+    pending = false;
   }
-  if (any) {
-    // Node::FromNodeCoords at every level from the hit node up to and including the root (src/core/node.cpp:127-139)
-    for (int a = h.node; a >= 0; a = instAt<false>(sc, a).parent) {
-      if (a == 0 && sc.rootIdentity) {
-        h.N = normalize(h.N);
-        break;
-      }
-      const qa_instance ia = instAt<false>(sc, a);
-      h.p = mulMV(ia.tm, h.p) + ld3(ia.pos);
-      h.N = normalize(mulTMV(ia.itm, h.N));
-    }
-  }
-  return any;
+  QA_TACC(cnt.sl[14], tDet)
+  return found;
 }
 
 // The shadow ray illuminate() (qa_kernel.h) shoots from p towards light l
@@ -451,116 +700,228 @@ __device__ __forceinline__ void csShadowRay(const qa_light &l, f3 p, Ray &w, flo
   }
 }
 
-// GenLight::Shadow -> Scene::TraceNodeShadow for every non-ambient light of the lanes with `lit`: bit j of the result =
-// light slot j occluded.  The reference stops at the first node that occludes; which node that is does not matter.
-__device__ __forceinline__ uint32_t csShadows(const DScene &sc, bool lit, f3 p, uint32_t *pool, uint32_t cap, uint32_t *stack, DCounters &cnt)
+// GenLight::Shadow -> Scene::TraceNodeShadow for the next batch of up to QA_CS_LIGHT_BATCH non-ambient lights (table index li
+// onwards; on return li is where the following batch starts and nb the lights taken), for the lanes with `lit`: bit jj of the
+// result = light jj of the batch occluded.  The reference stops at the first node that occludes; which one does not matter.
+// One loop over (light, instance) pairs with ONE place where the pool runs: when it is full, and after the last pair.
+__device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds &L, bool lit, f3 p, int &li, uint32_t &nb, DCounters &cnt)
 {
-  uint32_t occl = 0, j = 0;
-  for (int li = 0; li < sc.num_lights; ++li) {
-    const qa_light l = ldTable(sc.light + li);
-    if (l.type == QA_LIGHT_AMBIENT) continue;
-    Ray w;
-    float tmax;
-    csShadowRay(l, p, w, tmax);
-    if (lit) cnt.casts_shadow++;
-    const Ray r0 = rootRay<false>(sc, w);
-    GroupRay grp;
-    grp.node = -1;
-    grp.ray = r0;
-    bool open = lit;   // this lane's query is still undecided
-    for (int k = 1; k < sc.num_inst; ++k) {
-      const qa_instance in = instAt<false>(sc, k);
-      if (in.obj_type == QA_OBJ_NONE) continue;
-      if (!__any(open)) break;
-      const Ray r = localRayInGroup<false>(sc, k, r0, grp);
-      bool hit = false;
-      if (in.obj_type == QA_OBJ_SPHERE || in.obj_type == QA_OBJ_PLANE) {
-        Hit h;
-        h.z = tmax;
-        h.node = -1;
-        if (open) hit = (in.obj_type == QA_OBJ_SPHERE) ? hitSphere(r, h, k, false) : hitPlane(r, h, k, false);
-      } else {
-        hit = csAnyHitMesh(meshAt<false>(sc, in.mesh), open, r, tmax, pool, cap, stack, cnt);
-      }
-      if (open && hit) {
-        occl |= 1u << j;
-        open = false;
+  const unsigned lane = __lane_id();
+  uint32_t occl = 0, redo = 0;
+  for (uint32_t jj = 0; jj < QA_CS_LIGHT_BATCH; ++jj) L.res[jj * 64u + lane] = 0;
+  L.flags[lane] = 0;
+  uint32_t n = 0, nSlots = 0, jj = 0;
+  nb = 0;
+  bool last = false;
+  int k = sc.num_inst;   // (the first iteration fetches a light)
+  Ray w, r0;
+  w.p = w.d = r0.p = r0.d = F3(0, 0, 0);
+  float tmax = 0.f;
+  GroupRay grp;
+  grp.node = -1;
+  grp.ray = r0;
+  QA_T(tSweep)
+  for (;;) {
+    ++k;
+    if (k >= sc.num_inst) {
+      while (li < sc.num_lights && ldTable(sc.light + li).type == QA_LIGHT_AMBIENT) ++li;
+      if (li >= sc.num_lights || nb == QA_CS_LIGHT_BATCH) last = true;
+      else {
+        const qa_light l = ldTable(sc.light + li);
+        ++li;
+        jj = nb++;
+        csShadowRay(l, p, w, tmax);
+        cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
+        r0 = rootRay<false>(sc, w);
+        grp.node = -1;
+        k = 1;
       }
     }
-    ++j;
+    bool coop = false;
+    Ray r;
+    r.p = r.d = F3(0, 0, 0);
+    float pad = 0.f;
+    uint32_t rootWord = 0;
+    if (!last) {
+      const bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
+      if (!__any(open)) { k = sc.num_inst; continue; }          // settled for the whole wave: next light
+      const CsInst ci = ldTable(sc.csInst + k);
+      const int type = ci.type;
+      if (type == QA_OBJ_NONE) continue;
+      r = csLocalSweep(ci, r0, grp);
+      if (type != QA_OBJ_MESH) {
+        Hit hh;
+        hh.z = tmax;
+        hh.node = -1;
+        const bool hit = open && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, false) : hitPlane(r, hh, k, false));
+        if (hit) occl |= 1u << jj;
+        continue;
+      }
+      const bool go = open && csGate(ci, r, tmax);
+      coop = go && ci.useWide && insideCancelReach(ci, r.p);
+      if (go && !coop) redo |= 1u << jj;
+      pad = csPad(ci, r.p);
+      rootWord = ci.csRootWord;
+    }
+    unsigned long long mk = __ballot(coop);
+    uint32_t c = (uint32_t) __popcll(mk);
+    if (last ? n != 0 : (c != 0 && (nSlots + c > L.slots || n + c > L.capItems))) {
+      csRun<false>(sc, L, n, QA_FILL(cnt));
+      csSettleShadows(sc, L, nb, occl, redo);   // before the slots are reused
+      nSlots = 0;
+      coop = coop && !(((occl | redo) >> jj) & 1u);   // queries that run decided do not enter
+      mk = __ballot(coop);
+      c = (uint32_t) __popcll(mk);
+    }
+    if (last) break;
+    if (c) {
+      csEnter(L, mk, coop, r, tmax, jj, pad, rootWord, n, nSlots);
+      n += c;
+      nSlots += c;
+    }
+  }
+  QA_TACC(cnt.sl[17], tSweep)
+  // ---- the exact repeats
+  redo &= ~occl;
+#ifdef QA_STAMPS
+  if (lane == 0) cnt.sl[16] += (unsigned long long) __popcll(__ballot(lit && redo != 0));
+#endif
+  if (__any(lit && redo != 0)) {
+    int lj = li;   // walk the batch's lights backwards from where it ended
+    for (uint32_t j = nb; j-- > 0;) {
+      do { --lj; } while (ldTable(sc.light + lj).type == QA_LIGHT_AMBIENT);
+      const bool mine = lit && ((redo >> j) & 1u);
+      if (!__any(mine)) continue;
+      const qa_light l = ldTable(sc.light + lj);
+      Ray wj;
+      float tj;
+      csShadowRay(l, p, wj, tj);
+      if (mine && csExactShadow(sc.inst, sc.mesh, sc.num_inst, sc.rootIdentity, wj.p.x, wj.p.y, wj.p.z, wj.d.x, wj.d.y, wj.d.z, tj)) occl |= 1u << j;
+    }
   }
   return occl;
 }
 
-// directLight() of qa_kernel.h with the shadow factors known (1.0f multiplies exactly, 0.0f gives the same signed zeros)
-__device__ __forceinline__ f3 csDirectLight(const DScene &sc, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, uint32_t occl)
+// One light's term of MtlBlinn_PhotonMap::Shade's light loop (directLight of qa_kernel.h) with the shadow factor known
+// (1.0f multiplies exactly, 0.0f gives the same signed zeros)
+__device__ __forceinline__ f3 csLightTerm(const qa_light &l, float normCoefDI, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, bool occluded)
+{
+  const float vis = occluded ? 0.0f : 1.0f;
+  f3 I;
+  if (l.type == QA_LIGHT_DIRECT) I = ld3(l.intensity) * vis;
+  else {
+    const f3 dir = ld3(l.position) - p;
+    I = (ld3(l.intensity) * vis) * inverseSquareFalloff(dir);
+    if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, p);
+  }
+  const f3 intensity = I * normCoefDI;
+  const f3 Ld = normalize(-lightDirection(l, p));
+  const f3 H = normalize(V + Ld);
+  const float cosNL = qmax(0.f, dot(N, Ld));
+  const float cosNH = qmax(0.f, dot(N, H));
+  const f3 brdf = kd + ks * qpowf(cosNH, gloss);
+  return (intensity * cosNL) * brdf;
+}
+
+// Direct lighting of the lanes with `lit` (MtlBlinn_PhotonMap.cpp:481-498): every non-ambient light in table order, the
+// shadow queries of up to QA_CS_LIGHT_BATCH lights walked together.
+__device__ __forceinline__ f3 csDirectLight(const DScene &sc, const CsLds &L, bool lit, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, DCounters &cnt)
 {
   f3 sum = F3(0, 0, 0);
   const float normCoefDI = 1.f / (float) sc.num_lights;
-  uint32_t j = 0;
-  for (int li = 0; li < sc.num_lights; ++li) {
-    const qa_light l = ldTable(sc.light + li);
-    if (l.type == QA_LIGHT_AMBIENT) continue;
-    const float vis = ((occl >> j) & 1u) ? 0.0f : 1.0f;
-    ++j;
-    f3 I;
-    if (l.type == QA_LIGHT_DIRECT) I = ld3(l.intensity) * vis;
-    else {
-      const f3 dir = ld3(l.position) - p;
-      I = (ld3(l.intensity) * vis) * inverseSquareFalloff(dir);
-      if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, p);
+  int li = 0;
+  while (li < sc.num_lights) {
+    int lj = li;
+    uint32_t nb = 0;
+    const uint32_t occl = csShadowBatch(sc, L, lit, p, li, nb, cnt);
+    if (!nb) break;
+    for (uint32_t jj = 0; jj < nb; ++jj, ++lj) {
+      while (ldTable(sc.light + lj).type == QA_LIGHT_AMBIENT) ++lj;
+      const qa_light l = ldTable(sc.light + lj);
+      if (lit) sum = sum + csLightTerm(l, normCoefDI, p, N, V, kd, ks, gloss, (occl >> jj) & 1u);
     }
-    const f3 intensity = I * normCoefDI;
-    const f3 Ld = normalize(-lightDirection(l, p));
-    const f3 H = normalize(V + Ld);
-    const float cosNL = qmax(0.f, dot(N, Ld));
-    const float cosNH = qmax(0.f, dot(N, H));
-    const f3 brdf = kd + ks * qpowf(cosNH, gloss);
-    sum = sum + (intensity * cosNL) * brdf;
   }
   return sum;
 }
 
 // ---------------------------------------------------------------------------------------------
-// The kernel: qa_integrate<RES = false, LIGHTS, TEX, AREA = false> with section D cut where the wave meets for its
-// shadow walks.  Dynamic LDS as qa_integrate's: [traversal stacks | sample accumulators].
+// The kernel: qa_integrate<RES = false, LIGHTS, TEX, AREA = false> with its closest-hit query and its shadow queries done
+// by the whole wave.  Dynamic LDS per wave: CsLds + 6 x 64 sample accumulators (host: CsLdsWords).
 // Sections A, B and E are qa_integrate's text, repeated here on purpose: moving them into functions shared by both kernels
 // changes the register allocation of qa_integrate's LDS-resident variants - the Cornell-box kernel lost 8 % (13.0 -> 12.0
 // Gsamples/s) with only the tile fetch factored out (profiles/round02/session3_experiments.txt, item 14).
 // ---------------------------------------------------------------------------------------------
-// Waves per SIMD the register allocator must leave room for: three for the untextured variants (the walks' bookkeeping
-// and the owner rays spill at four: C5 1262 -> 1439, C4 4007 -> 4622 Msamples/s), four for the textured ones (C3 731 vs 711).
 #ifndef QA_CS_WAVES_NOTEX
-#define QA_CS_WAVES_NOTEX 3
+#define QA_CS_WAVES_NOTEX 4
 #endif
 #ifndef QA_CS_WAVES_TEX
 #define QA_CS_WAVES_TEX 4
 #endif
+__host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) { return items + 8u * slots + QA_CS_RES_WORDS + 64u + QA_LANE_SLOTS * 64u; }
+
+// shadeSurface (qa_kernel.h) OUT OF LINE.  Shading is where the register pressure peaks (table-driven powf / expf, the 32-tap
+// texture filter, the rejection loops of the glossy lobes); inlined into the kernel, the allocator answers those peaks by
+// keeping long-lived values of the WHOLE loop in scratch and reloading them inside the sweeps and rounds, where every reload is
+// a vector-memory round trip on the critical path.  As a function of its own it is allocated on its own; the kernel pays one
+// save / restore of its live registers per call instead.
+#ifndef QA_CS_SHADE_CALL
+#define QA_CS_SHADE_CALL(TEX) (!(TEX))   /* out of line for the untextured variants (A/B below) */
+#endif
+struct CsMtlTex { const int32_t *mtlTex; };
+template <bool TEX>
+__device__ __attribute__((noinline)) void csShade(const uint4 *mtlTable, const int32_t *mtlTex, const unsigned char *blob, const qa_texmap *texmap, const qa_texture *tex,
+                                                  const float *filter, int mi, f3 N, f3 V, bool front, TexHit th, int bounceLeft, bool fromDiffuse, uint32_t *rng,
+                                                  Surface *out)
+{
+  TexTables tt;
+  tt.blob = blob;
+  tt.texmap = texmap;
+  tt.tex = tex;
+  tt.filter = filter;
+  CsMtlTex mt;
+  mt.mtlTex = mtlTex;
+  uint32_t r = *rng;
+  *out = shadeSurface<TEX, CsMtlTex>(mtlTable, mt, tt, mi, N, V, front, th, bounceLeft, fromDiffuse, r);
+  *rng = r;
+}
+
+// What a path keeps between its segments besides its ray, throughput and radiance, in one word: bounceCount the next hit is
+// shaded with | hInfo.c.hasDiffuseHit of the next hit | camera ray | 1 + the material the ray was spawned from (its absorption
+// applies on a back-face exit: Beer's law, ComputeSecondaryRay MtlBlinn_PhotonMap.cpp:244-248; 0 for camera rays).
+#define QA_PST_BOUNCE(s) ((int) ((s) & 0xFFu))
+#define QA_PST_FROM_DIFFUSE 0x100u
+#define QA_PST_PRIMARY 0x200u
+#define QA_PST_ABSORB(s) ((int) ((s) >> 16) - 1)
+
 template <bool LIGHTS, bool TEX>
 __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
-  SceneMem<false> mem;
-  mem.img = s_dyn;
-  uint32_t *stack = reinterpret_cast<uint32_t *>(s_dyn) + threadIdx.x;
-  float *acc = reinterpret_cast<float *>(stack + (size_t) sc.stackDepth * QA_BLOCK - threadIdx.x) + threadIdx.x;
+  const unsigned lane = __lane_id();
+  CsLds L;
+  {
+    const uint32_t poolCap = (sc.csPoolLimit && sc.csPoolLimit < sc.csItems) ? sc.csPoolLimit : sc.csItems;   // (a limit below the LDS there is: tests of the overflow path)
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x / 64));                   // (wave-uniform: the pointers stay in scalar registers)
+    uint32_t *base = reinterpret_cast<uint32_t *>(s_dyn) + wave * CsLdsWords(sc.csItems, sc.csSlots);
+    L.rays = reinterpret_cast<uint4 *>(base);                     // 16-byte aligned: first
+    L.res = base + 8u * sc.csSlots;                               // 8-byte aligned keys
+    L.flags = L.res + QA_CS_RES_WORDS;
+    L.items = L.flags + 64;
+    L.capItems = poolCap;
+    L.slots = sc.csSlots;
+  }
+  float *acc = reinterpret_cast<float *>(L.items + sc.csItems) + lane;   // + i * 64
   const uint4 *mtlTable = reinterpret_cast<const uint4 *>(sc.mtl);
-  // the wave's pool for cooperative walks: its own columns of the per-lane stacks
-  uint32_t *pool = reinterpret_cast<uint32_t *>(s_dyn) + (threadIdx.x / 64) * 64;
-  // behind the pool: result words / keys and flags (csWalkAny, csWalkClosest).  (A limit below the LDS there is: tests of the overflow path.)
-  const uint32_t poolRoom = sc.stackDepth * 64u - 192u;
-  const uint32_t poolCap = (sc.csPoolLimit && sc.csPoolLimit < poolRoom) ? (sc.csPoolLimit & ~63u) : poolRoom;
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
   const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
-  const unsigned lane = __lane_id();
 
   DCounters cnt = {};
 #ifdef QA_STAMPS
-  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][13];
+  __shared__ unsigned long long s_stamps[QA_BLOCK / 64][QA_NSTAMPS];
   cnt.sl = s_stamps[threadIdx.x / 64];
-  if (__lane_id() < 13) cnt.sl[__lane_id()] = 0;
+  if (__lane_id() < QA_NSTAMPS) cnt.sl[__lane_id()] = 0;
 #endif
   QA_T(tKernel)
   TexTables tt;
@@ -568,23 +929,17 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   tt.texmap = sc.texmap;
   tt.tex = sc.tex;
   tt.filter = sc.texFilter;
-  RayDiff pathDiff;
-  pathDiff.dx = pathDiff.dy = F3(0, 0, 1);
 
-  int px = 0, py = 0;
+  // per-lane state: pixel (x | y << 16, output index, RNG stream, sample index) and path (ray, throughput, radiance, state word)
+  uint32_t pxy = 0;
   unsigned q = 0;
   uint32_t rng = 1;
   int sidx = 0;
-  Path path;
-  path.primary = true;
-  path.ray.p = F3(0, 0, 0);
-  path.ray.d = F3(0, 0, 1);
-  path.T = F3(0, 0, 0);
-  path.L = F3(0, 0, 0);
-  path.absorbMtl = -1;
-  path.bounce = 0;
-  path.fromDiffuse = false;
-  f3 texpos = F3(0, 0, 0);
+  Ray ray;
+  ray.p = F3(0, 0, 0);
+  ray.d = F3(0, 0, 1);
+  f3 pT = F3(0, 0, 0), pL = F3(0, 0, 0);
+  uint32_t pst = QA_PST_PRIMARY;
   bool alive = true, needPixel = true, needSample = false;
 
   for (;;) {
@@ -608,12 +963,12 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           const unsigned tx = (tile % tilesX) * 8 + (in % 8);
           const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
           if (tx < (unsigned) rw && ty < (unsigned) rh) {
-            px = rp.x0 + (int) tx;
-            py = rp.y0 + (int) ty;
+            const uint32_t px = (uint32_t) rp.x0 + tx, py = (uint32_t) rp.y0 + ty;
+            pxy = px | (py << 16);
             q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
-            rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
+            rng = qa_pixel_seed(rp.seed, py * (uint32_t) sc.cam.width + px);
             sidx = 0;
-            for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;
+            for (int i = 0; i < 6; ++i) acc[i * 64] = 0.f;
             needSample = true;
             needPixel = false;
           }
@@ -624,9 +979,10 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
 
     // ---- B. start a sample (qa_integrate, section B; src/renderers/renderer.cpp:312-328)
     const bool goSample = !rp.sync_samples || (__ballot(needSample) == __ballot(alive && !needPixel));
-    if (alive && needSample && goSample) {
-      const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
-      texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
+    const bool starting = alive && needSample && goSample;
+    cnt.samples += (unsigned long long) __popcll(__ballot(starting));   // (wave-uniform tallies: no registers per lane)
+    if (starting) {
+      const f3 texpos = csTexPos(sc, pxy, sidx);
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
       const f3 cpt = (A + U * texpos.x) + V * texpos.y;
       f3 campos = ld3(sc.cam.pos);
@@ -636,40 +992,21 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         const float t = r2 * 2.f * QA_PI;
         campos = campos + (ld3(sc.cam.screenX) * (r * qcosf(t)) + ld3(sc.cam.screenY) * (r * qsinf(t)));
       }
-      path.ray.p = campos;
-      path.ray.d = normalize(cpt - campos);
-      if (TEX) {
-        const f3 xpt = (A + U * (texpos.x + QA_DX)) + V * texpos.y;
-        const f3 ypt = (A + U * texpos.x) + V * (texpos.y + QA_DX);
-        pathDiff.dx = normalize(xpt - campos);
-        pathDiff.dy = normalize(ypt - campos);
-      }
-      path.T = F3(1, 1, 1);
-      path.L = F3(0, 0, 0);
-      path.absorbMtl = -1;
-      path.bounce = rp.max_bounce;
-      path.fromDiffuse = false;
-      path.primary = true;
+      ray.p = campos;
+      ray.d = normalize(cpt - campos);
+      pT = F3(1, 1, 1);
+      pL = F3(0, 0, 0);
+      pst = QA_PST_PRIMARY | (uint32_t) (rp.max_bounce & 0xFF);
       needSample = false;
-      cnt.samples++;
     }
     QA_TACC(cnt.sl[1], tA)
     // ---- C. trace (qa_integrate, section C)
     const bool act = alive && !needPixel && !needSample;
     bool done = false;
     Hit h;
-    h.z = QA_BIGFLOAT;
-    h.node = -1;
-    h.mtlID = 0;
-    h.front = true;
-    h.p = F3(0, 0, 0);
-    h.N = F3(0, 0, 0);
     TexHit th;
-    th.uvw = F3(0.5f, 0.5f, 0.5f);
-    th.duvw0 = th.duvw1 = F3(0, 0, 0);
-    th.hasTexture = false;
     QA_T(tC)
-    const bool found = csTraceClosest<TEX>(sc, act, path.ray, pathDiff, h, th, pool, poolCap, stack, cnt);
+    const bool found = csTraceClosest<TEX>(sc, L, act, ray, (pst & QA_PST_PRIMARY) != 0, pxy, sidx, h, th, cnt);
     QA_TACC(cnt.sl[2], tC)
     QA_T(tD)
 
@@ -682,22 +1019,25 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     sf.gloss = 0.f;
     sf.spawn = sf.nextFromDiffuse = sf.selDiffuse = false;
     if (act) {
-      if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
+      const bool primary = (pst & QA_PST_PRIMARY) != 0;
+      if (primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
       if (!found) {
-        f3 c = path.primary ? ld3(sc.background) : ld3(sc.environment);
+        f3 c = primary ? ld3(sc.background) : ld3(sc.environment);
         if (TEX) {
-          if (path.primary)
+          if (primary) {
+            const f3 texpos = csTexPos(sc, pxy, sidx);
             c = texColorSample(tt, c, sc.bgTexmap, F3(texpos.x / (float) sc.cam.width, texpos.y / (float) sc.cam.height, 0.f));
-          else
-            c = sampleEnvironment(tt, c, sc.envTexmap, path.ray.d);
+          } else
+            c = sampleEnvironment(tt, c, sc.envTexmap, ray.d);
         }
-        path.L = path.L + path.T * c;
+        pL = pL + pT * c;
         done = true;
       } else {
-        if (!path.primary && !h.front && path.absorbMtl >= 0) {
-          const uint4 ab = mtlTable[6 * (size_t) path.absorbMtl + 5];
+        const int absorbMtl = QA_PST_ABSORB(pst);
+        if (!primary && !h.front && absorbMtl >= 0) {
+          const uint4 ab = mtlTable[6 * (size_t) absorbMtl + 5];
           const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
-          path.T = path.T * att;
+          pT = pT * att;
         }
         const qa_instance &in = sc.inst[h.node];
         bool white = false;
@@ -709,14 +1049,17 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           } else mi = ms.first;
         }
         if (mi < 0) {
-          if (white) path.L = path.L + path.T;
+          if (white) pL = pL + pT;
           done = true;
         } else {
-          V = -path.ray.d;
+          V = -ray.d;
           N = h.N;
           p = h.p;
-          sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, path.bounce, path.fromDiffuse, rng);
-          path.L = path.L + path.T * sf.emission;
+          if (QA_CS_SHADE_CALL(TEX))
+            csShade<TEX>(mtlTable, sc.mtlTex, tt.blob, tt.texmap, tt.tex, tt.filter, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, &rng, &sf);
+          else
+            sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, rng);
+          pL = pL + pT * sf.emission;
           lit = true;
         }
       }
@@ -726,37 +1069,35 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     if (LIGHTS) {
       if (__any(lit)) {
         QA_T(tL)
-        const uint32_t occl = csShadows(sc, lit, p, pool, poolCap, stack, cnt);
-        if (lit) path.L = path.L + path.T * csDirectLight(sc, p, N, V, sf.kd, sf.ks, sf.gloss, occl);
+        const f3 dl = csDirectLight(sc, L, lit, p, N, V, sf.kd, sf.ks, sf.gloss, cnt);
+        if (lit) pL = pL + pT * dl;
         QA_TACC(cnt.sl[5], tL)
       }
     }
     QA_T(tE)
     if (lit) {
       if (sf.spawn) {
-        path.ray.p = p;
-        path.ray.d = normalize(sf.nextDir);
-        if (TEX) pathDiff.dx = pathDiff.dy = path.ray.d;
-        path.T = path.T * sf.bxdf;
-        path.absorbMtl = mi;
-        path.bounce -= 1;
-        path.fromDiffuse = sf.nextFromDiffuse;
-        path.primary = false;
+        // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
+        ray.p = p;
+        ray.d = normalize(sf.nextDir);
+        pT = pT * sf.bxdf;
+        pst = (uint32_t) ((QA_PST_BOUNCE(pst) - 1) & 0xFF) | (sf.nextFromDiffuse ? QA_PST_FROM_DIFFUSE : 0u) | ((uint32_t) (mi + 1) << 16);
       } else {
         done = true;
       }
     }
 
     // ---- E. sample finished (qa_integrate, section E; scene.cpp:92-121)
+    bool pixelDone = false;
     if (alive && done) {
       const float inv = (float) (sidx + 1);
-      f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
-      f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
-      const f3 dc = (path.L - mean) / inv;
+      f3 mean = F3(acc[0], acc[64], acc[2 * 64]);
+      f3 cstd = F3(acc[3 * 64], acc[4 * 64], acc[5 * 64]);
+      const f3 dc = (pL - mean) / inv;
       mean = mean + dc;
       if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
-      acc[0] = mean.x; acc[QA_BLOCK] = mean.y; acc[2 * QA_BLOCK] = mean.z;
-      acc[3 * QA_BLOCK] = cstd.x; acc[4 * QA_BLOCK] = cstd.y; acc[5 * QA_BLOCK] = cstd.z;
+      acc[0] = mean.x; acc[64] = mean.y; acc[2 * 64] = mean.z;
+      acc[3 * 64] = cstd.x; acc[4 * 64] = cstd.y; acc[5 * 64] = cstd.z;
       ++sidx;
       const bool more = sidx < rp.spp_min || (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
@@ -766,28 +1107,30 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
         rp.ns[q] = (uint32_t) sidx;
-        cnt.pixels++;
+        pixelDone = true;
         needPixel = true;
       }
     }
+    cnt.pixels += (unsigned long long) __popcll(__ballot(pixelDone));
     QA_TACC(cnt.sl[7], tE)
 #ifdef QA_STAMPS
     if (lane == 0) cnt.sl[8] += 1;
 #endif
   }
 
-  unsigned long long v[6] = {cnt.samples, cnt.casts_normal, cnt.casts_shadow, cnt.bvh_nodes, cnt.tri_tests, cnt.pixels};
+  // the tallies are per wave: one lane adds them
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(rp.counters);
-  for (int i = 0; i < 6; ++i) {
-    unsigned long long x = v[i];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if (lane == 0 && x) atomicAdd(&dst[i], x);
+  if (lane == 0) {
+    if (cnt.samples) atomicAdd(&dst[0], cnt.samples);
+    if (cnt.casts_normal) atomicAdd(&dst[1], cnt.casts_normal);
+    if (cnt.casts_shadow) atomicAdd(&dst[2], cnt.casts_shadow);
+    if (cnt.pixels) atomicAdd(&dst[5], cnt.pixels);
   }
 #ifdef QA_STAMPS
   if (lane == 0) {
     cnt.sl[0] = __builtin_readcyclecounter() - tKernel;
     cnt.sl[9] = 1;
-    for (int i = 0; i < 13; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
+    for (int i = 0; i < QA_NSTAMPS; ++i) atomicAdd(&dst[6 + i], cnt.sl[i]);
   }
 #endif
 }

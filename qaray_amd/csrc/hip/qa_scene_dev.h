@@ -115,6 +115,8 @@ struct DMesh {
   uint32_t wideStack;          // stack entries a walk of the wide tree can need (3 per level + 2)
   float nearPad;               // fp32 slack of the reference's inside test (qa_widebvh.h ComputeMeshSlack)
   float cancelDist;            // ray origins farther out than this keep the reference tree
+  uint32_t csRootWord;         // root of this mesh's 4-wide tree inside the scene-wide arrays DScene::csNodes / csTris (qa_kernel_cs.h)
+  uint32_t csPad;
 };
 
 // The widening of the own search trees' boxes and the parallelism / cancellation guards (qa_kernel.h hitMesh, qa_wf.h,
@@ -124,6 +126,22 @@ struct DMesh {
 #ifndef QA_SLACK_SCALE
 #define QA_SLACK_SCALE 1.0f
 #endif
+
+// qa_integrate_cs's view of a scene-graph node: everything a sweep over the instances needs in ONE record (one group of
+// scalar loads per instance instead of the chain instance -> parent -> ... -> mesh descriptor).  Levels: the transforms between
+// the root's space and the node's own, outermost first (A, then B for a node inside a group; deeper nesting keeps qa_integrate).
+struct alignas(64) CsInst {
+  float itmA[9], posA[3];
+  float itmB[9], posB[3];
+  float tmA[9], tmB[9];        // Node::FromNodeCoords of the two levels
+  int32_t type, depth;         // QA_OBJ_*, 1 or 2
+  uint32_t useWide, csRootWord, num_faces, mesh;
+  float bmin[3], bmax[3];      // mesh bounds (node space)
+  float nearPad, absMax, cancelDist;
+  float wmin[3], wmax[3];      // bounds of the object in ROOT space, padded (instance culling)
+  int32_t parent;              // depth 2: the group node (consecutive children of one group share its level-A ray)
+};
+static_assert(sizeof(CsInst) == 256, "CsInst must be 64 dwords");
 
 #define QA_LANE_SLOTS 6   /* per-lane LDS floats behind the traversal stack: running mean and variance of the pixel */
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
@@ -158,7 +176,15 @@ struct DScene {
   uint32_t rootIdentity;       // instance 0 has tm = itm = I and pos = 0 (always, for XML scenes)
   uint32_t stackDepth;         // entries per lane of the LDS traversal stack
   int32_t bgTexmap, envTexmap; // texmaps of the background / environment colours (-1 = none)
-  uint32_t csPoolLimit;        // qa_integrate_cs: upper bound for the pool capacity (0 = none; QA_CS_POOL, tests: forces the overflow path)
+  uint32_t csPoolLimit;        // qa_integrate_cs: upper bound for the pool capacity (0 = none; option "cs_pool_limit", tests: forces the overflow path)
+  // qa_integrate_cs (qa_kernel_cs.h): the 4-wide trees of ALL meshes in one node array and one triangle array (child words and
+  // leaf ranges rebased), so that a pool item needs no mesh: csNodes[4 * node], csTris[3 * triangle]; csLeafBox[2 * triangle] =
+  // box of the triangle's leaf in the REFERENCE tree (6 floats, then 1.0f when that leaf is the root: always reached)
+  const uint4 *csNodes;
+  const uint4 *csTris;
+  const uint4 *csLeafBox;
+  const CsInst *csInst;        // [num_inst]
+  uint32_t csItems, csSlots;   // per-wave pool capacity (items) and ray slots of the LDS layout
   // resident scenes only: the tables themselves, in the kernel-argument segment
   qa_instance instv[QA_KARG_INST];
   DMesh meshv[QA_KARG_MESH];
@@ -171,7 +197,10 @@ struct DCounters {
   // over waves, printed by qa_get_counters: 0 kernel, 1 fetch + sample start, 2 closest-hit queries, 3 of which mesh walks,
   // 4 shadeSurface, 5 direct light, 6 of which shadow mesh walks, 7 sample end, 8 loop iterations, 9 waves, 10 miss branch,
   // 11 hit before shading, 12 spawn.
-  unsigned long long stamp[13];
+  // qa_integrate_cs also: 13 closest-hit sweep without the rounds, 14 details of the winners, 15 lanes sent to the exact closest-hit
+  // walk, 16 (lane, light) pairs sent to the exact shadow walk, 17 shadow sweeps without the rounds, 18 light terms
+#define QA_NSTAMPS 20
+  unsigned long long stamp[QA_NSTAMPS];
   unsigned long long *sl;   // device side: the wave's accumulators in LDS (one elected lane adds: a section entered by part of the wave counts in full)
 #endif
 };

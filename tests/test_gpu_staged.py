@@ -349,9 +349,10 @@ def test_auto_is_the_megakernel_and_staged_runs_on_request_only():
         assert np.array_equal(bits(x), bits(y)) and np.array_equal(bits(x), bits(z))
 
 
-def test_more_than_32_lights_keep_the_per_lane_kernel(tmp_path):
-    """csShadows keeps one occlusion bit per non-ambient light in a 32-bit mask; a scene with 33 lights over a global-memory
-    mesh must not take the cooperative kernel (lights 32.. would alias onto earlier bits), and renders like the oracle."""
+def test_many_lights_are_pooled_in_batches(tmp_path):
+    """34 non-ambient lights over a global-memory mesh: the cooperative kernel pools their shadow queries four lights at a
+    time (round 2's kernel kept one occlusion bit per light in a 32-bit mask: lights 32.. aliased).  Same bits as the per-lane
+    kernel, depth / cast counts as the oracle."""
     from oracle import binding as oracle
     from qaray_amd import hip
     from qaray_amd.host import load_scene_blob
@@ -363,17 +364,23 @@ def test_more_than_32_lights_keep_the_per_lane_kernel(tmp_path):
     open(xml, "w").write(txt)
     w, h, spp = 96, 72, 2
     blob = load_scene_blob(xml, size=(w, h), asset_root=str(tmp_path))
-    c = hip.Context(0)
-    c.upload_scene(blob)
-    assert c.kernel_name().startswith("qa_integrate<RES=0"), c.kernel_name()   # 34 non-ambient lights
-    c.reset_counters()
-    rgb, depth, ns = c.render_region((0, 0, w, h), spp)
-    cnt = c.counters()
-    c.close()
+    outs, cnts = {}, {}
+    for mode in ("coop", "own"):
+        c = hip.Context(0)
+        c.set_option("coop", 1 if mode == "coop" else 0)
+        c.upload_scene(blob)
+        assert ("qa_integrate_cs" in c.kernel_name()) == (mode == "coop"), c.kernel_name()
+        c.reset_counters()
+        outs[mode] = c.render_region((0, 0, w, h), spp)
+        cnts[mode] = c.counters()
+        c.close()
+    for a, b in zip(outs["coop"], outs["own"]):
+        assert np.array_equal(bits(a), bits(b))
+    assert cnts["coop"] == cnts["own"]
     o = oracle.render(blob, (0, 0, w, h), spp)
-    assert np.array_equal(bits(depth), bits(o[1])) and np.array_equal(ns, o[2])
-    assert (cnt["casts_normal"], cnt["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
-    assert rmse(np.nan_to_num(rgb), np.nan_to_num(o[0])) <= RMSE_TOL
+    assert np.array_equal(bits(outs["coop"][1]), bits(o[1])) and np.array_equal(outs["coop"][2], o[2])
+    assert (cnts["coop"]["casts_normal"], cnts["coop"]["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
+    assert rmse(np.nan_to_num(outs["coop"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
 
 
 def test_stop_request_ends_a_staged_frame(ctx):
