@@ -94,6 +94,68 @@ def cpu_baseline(scene_xml, width, height, spp, seed):
             "sample": sample, "seconds": dt}
 
 
+def committed_traffic(kernel_name, scene, W, H, spp):
+    """Measured HBM-side bytes per launch of the same kernel on the same frame, from the rocprofv3 --pmc passes committed
+    under profiles/ (tools/summarize_profiles.py writes the *_summary.json files)."""
+    best = None
+    try:
+        prof_dir = os.path.join(ROOT, "profiles")
+        for d in sorted(os.listdir(prof_dir)):
+            for f in sorted(os.listdir(os.path.join(prof_dir, d))):
+                if f.endswith("_summary.json"):
+                    sj = json.load(open(os.path.join(prof_dir, d, f)))
+                    if (sj.get("frame") == [W, H] and sj.get("spp") == spp and "hbm_traffic_bytes_per_launch" in sj
+                            and sj.get("kernel_name") == kernel_name.split(" (")[0] and sj.get("scene") == scene):
+                        best = (sj, os.path.join("profiles", d, f))
+    except Exception:
+        pass
+    return best
+
+
+CPU_SAMPLE_SPP = {"c3": 24, "c4": 10, "c5": 6}   # bounded CPU samples of >= 5 s on 16 host threads (4.1 / 13.1 / 7.3 Msamples/s in round 2)
+
+
+def other_config(ctx, tag, args, torch, hip, qd, load_scene_blob, SCENES_DIR, device):
+    """One full-spp step of BASELINE config `tag` on this GPU (scene resident, HIP events around the launch), its roofline
+    entry and a CPU-baseline sample of the same frame.  -> dict for the bench line's 'other_configs'."""
+    cfg = CONFIGS[tag]
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    scene_xml = os.path.join(SCENES_DIR, cfg["scene"])
+    blob = load_scene_blob(scene_xml, size=(W, H))
+    ctx.upload_scene_device(torch.from_numpy(blob).to(device))
+    bufs = qd.StripBuffers(H, W, device)
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        ctx.render_region_device((0, 0, 64, 64), 1, bufs.rgb[:64, :64].contiguous(), bufs.depth[:64, :64].contiguous(),
+                                 bufs.ns[:64, :64].contiguous(), max_bounce=args.bounce, seed=args.seed, stream=side.cuda_stream)   # warm-up (code, tables)
+        torch.cuda.synchronize()
+        ctx.reset_kernel_time()
+        ctx.reset_counters()
+        t0 = time.perf_counter()
+        ctx.render_region_device((0, 0, W, H), spp, bufs.rgb, bufs.depth, bufs.ns, max_bounce=args.bounce, seed=args.seed, stream=side.cuda_stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    k_ms, launches = ctx.kernel_time()
+    cnt = ctx.counters()
+    kernel_name = ctx.kernel_name()
+    casts = cnt["casts_normal"] + cnt["casts_shadow"]
+    k_bytes = casts * BYTES_PER_CAST + cnt["samples"] * BYTES_PER_SAMPLE
+    achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    out = {"workload": f"inputs/{cfg['scene']} ({cfg['what']}), {W}x{H}, {spp} spp", "steps": 1,
+           "value": cnt["samples"] / elapsed * 1e-6, "unit": "Msamples/s", "ms_per_step": elapsed * 1e3,
+           "casts_per_sample": casts / max(cnt["samples"], 1),
+           "roofline": {"bound": "latency (see actual_limiter of the headline entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name, "kernel_ms_avg": k_ms / max(launches, 1),
+                        "algorithmic_bytes_per_launch": k_bytes}}
+    best = committed_traffic(kernel_name, cfg["scene"], W, H, spp)
+    if best:
+        out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = best[1]
+    if args.cpu_spp > 0:
+        out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, CPU_SAMPLE_SPP[tag], args.seed)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +180,11 @@ def main():
                          "e.g. --photon-map 10000 20 0.2 1000 20 1.0")
     ap.add_argument("--check", action="store_true",
                     help="rank 0: also render the whole frame alone and require the gathered image to equal it bit for bit")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="create the process group and run broadcast + gather with ONE rank too (the RCCL path on a one-GPU box; "
+                         "launch under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the one full-spp step of BASELINE's c3 / c4 / c5 that the default N=1 line carries in 'other_configs'")
     args = ap.parse_args()
     cfg = CONFIGS[args.config or "c2"]
     strong = bool(args.config) and cfg["strong"]
@@ -144,7 +211,10 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collectives
+    if collective:
+        if "RANK" not in os.environ:   # --force-collectives without a launcher: a one-rank group of our own
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -160,7 +230,7 @@ def main():
         ctx.set_option("staged_groups", 4)   # with GPU_MAX_HW_QUEUES=8 (set above, before HIP initialises)
     # rank 0 parses + flattens; everyone receives the blob over RCCL and adopts it from HBM
     blob = load_scene_blob(scene_xml, size=(W, H)) if rank == 0 else None
-    if world > 1:
+    if collective:
         dblob = qd.broadcast_blob(blob, coll_device, src=0).to(device)
     else:
         dblob = torch.from_numpy(blob).to(device)
@@ -172,9 +242,9 @@ def main():
     nstrips = hip.strip_count(0, H, rank, world)
     maxstrips = qd.max_strips_per_rank(H, world)
     rows = maxstrips * qd.STRIP_ROWS          # equal shapes on every rank for the gather
-    rgb = torch.zeros((rows, W, 3), dtype=torch.float32, device=device)
-    depth = torch.zeros((rows, W), dtype=torch.float32, device=device)
-    ns = torch.zeros((rows, W), dtype=torch.int32, device=device)
+    # colour, z-buffer and sample counts of this rank's strips in ONE flat buffer: the frame is gathered in one collective
+    bufs = qd.StripBuffers(rows, W, device)
+    rgb, depth, ns = bufs.rgb, bufs.depth, bufs.ns
     # One explicit stream for the kernel AND everything that consumes its output (the RCCL gather,
     # the host copy of the gloo rehearsal, the strip assembly): torch.distributed orders collectives
     # after the work already queued on torch's current stream, so the step runs with this stream
@@ -195,16 +265,16 @@ def main():
         if nstrips:
             ctx.render_strips_device((0, 0, W, H), rank, world, args.spp, rgb[:nown], depth[:nown], ns[:nown],
                                      max_bounce=args.bounce, seed=args.seed, stream=stream)
-        if world > 1:
-            g = qd.gather_packed(rgb if args.backend == "nccl" else rgb.cpu(), dst=0)
+        if collective:
+            g = qd.gather_packed(bufs.flat if args.backend == "nccl" else bufs.flat.cpu(), dst=0, force=True)
             if rank == 0:
-                full = qd.assemble(g, H, world)
+                full = qd.assemble_frame(g, rows, W, H, world)   # (rgb, depth, sample counts)
         else:
-            full = rgb[:H]
+            full = (rgb[:H], depth[:H], ns[:H])
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -218,7 +288,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -228,7 +298,7 @@ def main():
     kernel_name = ctx.kernel_name()
     staged = ctx.staged_stats() if kernel_name.startswith("staged") else None
     local = torch.tensor([cnt["samples"], cnt["casts_normal"], cnt["casts_shadow"]], dtype=torch.float64, device=coll_device)
-    if world > 1:
+    if collective:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)
     samples, casts_n, casts_s = (float(v) for v in local.tolist())
 
@@ -286,35 +356,43 @@ def main():
             out["roofline"]["trace_lane_utilisation"] = staged["lane_utilisation"]
             out["roofline"]["staged"] = {k: staged[k] for k in ("passes", "jobs_done", "node_steps", "tri_tests", "rays_redone", "jobs_suspended")}
         # measured HBM traffic of the same kernel on the same frame, from the committed rocprofv3 --pmc passes
-        try:
-            prof_dir = os.path.join(ROOT, "profiles")
-            best = None
-            for d in sorted(os.listdir(prof_dir)):
-                for f in sorted(os.listdir(os.path.join(prof_dir, d))):
-                    if f.endswith("_summary.json"):
-                        sj = json.load(open(os.path.join(prof_dir, d, f)))
-                        if (sj.get("frame") == [W, H] and sj.get("spp") == args.spp and "hbm_traffic_bytes_per_launch" in sj
-                                and sj.get("kernel_name") == kernel_name.split(" (")[0] and sj.get("scene") == os.path.basename(scene_xml)):
-                            best = (sj, os.path.join("profiles", d, f))
-            if best:
-                out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
-                out["roofline"]["measured_hbm_gbs"] = best[0]["hbm_traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-                out["roofline"]["traffic_source"] = (best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes; measured on build "
-                                                     + str(best[0].get("build", "?")) + ")")
-        except Exception:
-            pass
+        best = committed_traffic(kernel_name, os.path.basename(scene_xml), W, H, args.spp)
+        if best:
+            out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
+            out["roofline"]["measured_hbm_gbs"] = best[0]["hbm_traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+            out["roofline"]["traffic_source"] = (best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes: an UPPER bound for HBM, "
+                                                 "the counters also see Infinity-Cache hits; measured on build " + str(best[0].get("build", "?")) + ")")
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, args.cpu_spp, args.seed)
+        # the default one-GPU line also carries ONE full-spp step of BASELINE's other three configs (the driver only runs this command)
+        default_line = (world == 1 and not collective and args.config is None and headline and (args.spp, W, H) == (512, 1920, 1080)
+                        and not args.photon_map and args.pipeline == "auto")
+        if default_line and not args.no_other_configs:
+            subprocess.run([sys.executable, os.path.join(ROOT, "scenes", "gen_assets.py")], check=True, stdout=subprocess.DEVNULL)
+            out["other_configs"] = {}
+            for tag in ("c3", "c4", "c5"):
+                try:
+                    out["other_configs"][tag] = other_config(ctx, tag, args, torch, hip, qd, load_scene_blob, SCENES_DIR, device)
+                except Exception as e:   # never lose the headline line to a side measurement
+                    out["other_configs"][tag] = {"error": repr(e)}
+        if collective:
+            out["collectives"] = {"backend": args.backend, "world": world, "broadcast": "flat scene blob (uint8)",
+                                  "gather": "one flat float32 buffer per rank: rgb | depth | sample counts (Renderer_MPI.cpp:194-207)"}
         if args.check:
-            alone = ctx.render_region((0, 0, W, H), args.spp, max_bounce=args.bounce, seed=args.seed)[0]
-            out["check"] = bool(np.array_equal(alone.view(np.uint32), full.cpu().numpy().view(np.uint32)))
+            alone = ctx.render_region((0, 0, W, H), args.spp, max_bounce=args.bounce, seed=args.seed)
+            got = [t.cpu().numpy() for t in full]
+            out["check"] = bool(all(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+                                    for a, b in zip(alone, got)))
         if args.save_png:
+            # the reference's three images (Renderer_MPI.cpp:130-139) from the GATHERED arrays: <prefix>colorBuffer.png, ...
             fb = FrameBuffer(W, H)
-            fb.deposit(0, 0, W, H, full.cpu().numpy(), np.zeros((H, W), np.float32),
-                       np.full((H, W), args.spp, np.uint32), args.spp, use_srgb=True)
-            fb.save_image(args.save_png)
+            fb.deposit(0, 0, W, H, full[0].cpu().numpy(), full[1].cpu().numpy(), full[2].cpu().numpy().astype(np.uint32), args.spp, use_srgb=True)
+            prefix = args.save_png[:-4] if args.save_png.endswith(".png") else args.save_png
+            fb.save_image(args.save_png if args.save_png.endswith(".png") else prefix + "colorBuffer.png")
+            fb.save_z_image(prefix + "depthBuffer.png")
+            fb.save_sample_count_image(prefix + "sampleBuffer.png")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

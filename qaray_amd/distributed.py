@@ -50,16 +50,44 @@ def broadcast_blob(blob_np, device, src=0):
     return t
 
 
-def gather_packed(packed, dst=0):
-    """Gather equally-shaped packed strip tensors to rank `dst` -> list of tensors (None elsewhere)."""
+def gather_packed(packed, dst=0, force=False):
+    """Gather equally-shaped packed strip tensors to rank `dst` -> list of tensors (None elsewhere).
+    force: issue the collective with one rank too (exercises the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    if world == 1:
+    if world == 1 and not force:
         return [packed]
     out = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
     dist.gather(packed, gather_list=out, dst=dst)
     return out
+
+
+class StripBuffers:
+    """A rank's packed strips of ALL arrays the reference gathers (colour, z-buffer, sample count; the mask is
+    `sample count != 0`: src/renderers/Renderer_MPI.cpp:194-207) in ONE flat float32 tensor, so that the frame travels in
+    one collective: [rgb rows*W*3 | depth rows*W | sample counts rows*W (int32 bits)]."""
+
+    def __init__(self, rows, width, device):
+        import torch
+        self.rows, self.width = rows, width
+        n = rows * width
+        self.flat = torch.zeros(5 * n, dtype=torch.float32, device=device)
+        self.rgb = self.flat[:3 * n].view(rows, width, 3)
+        self.depth = self.flat[3 * n:4 * n].view(rows, width)
+        self.ns = self.flat[4 * n:].view(torch.int32).view(rows, width)
+
+    @staticmethod
+    def views(flat, rows, width):
+        import torch
+        n = rows * width
+        return flat[:3 * n].view(rows, width, 3), flat[3 * n:4 * n].view(rows, width), flat[4 * n:].view(torch.int32).view(rows, width)
+
+
+def assemble_frame(gathered_flat, rows, width, height, world):
+    """Rank 0: the gathered flat buffers of every rank -> (rgb [H,W,3], depth [H,W], sample counts [H,W])."""
+    parts = [StripBuffers.views(g, rows, width) for g in gathered_flat]
+    return tuple(assemble([p[i] for p in parts], height, world) for i in range(3))
 
 
 _ROW_INDEX_CACHE = {}

@@ -502,3 +502,56 @@ def test_strong_scaling_rehearsal_of_baseline_multi_gpu_configs(ranks, config, s
     assert d["n_gpus"] == ranks and d["check"] is True and d["scaling"] == "strong"
     assert d["config"]["frame"] == list(size) and d["config"]["baseline_config"] == config
 
+
+
+def test_rccl_path_with_one_rank_broadcast_gather_and_all_three_images(tmp_path):
+    """The RCCL ("nccl") branch of bench.py on the one GPU there is: torch.distributed.run --nproc-per-node 1 with the process
+    group FORCED (init_process_group(device_id), uint8 blob broadcast, dist.gather of the flat colour | depth | sample-count
+    buffer on the step's stream, assembly), --check (gathered arrays == the frame rendered alone, bit for bit: all three
+    arrays the reference gathers, Renderer_MPI.cpp:194-207) and the three PNGs written from the GATHERED arrays."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    prefix = str(tmp_path / "g_")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-collectives", "--check",
+           "--steps", "2", "--warmup", "1", "--spp", "4", "--width", "320", "--height", "180", "--cpu-spp", "0", "--save-png", prefix]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["check"] is True
+    assert d["collectives"]["backend"] == "nccl" and d["collectives"]["world"] == 1
+    for name in ("colorBuffer.png", "depthBuffer.png", "sampleBuffer.png"):
+        assert os.path.getsize(prefix + name) > 100, name
+
+
+@pytest.mark.parametrize("scene,size,spp", [("example_project7_object.xml", (1920, 1080), 8),
+                                            ("example_project12_caustics_glossy.xml", (3840, 2160), 4),
+                                            ("trc_scene_tower.xml", (3840, 2160), 4)])
+def test_cooperative_kernel_equals_the_reference_walk_at_the_quoted_frame_sizes(scene, size, spp):
+    """qa_integrate_cs against the counting kernel (the reference's cy::BVH walked as the reference walks it) on the WHOLE
+    1080p / 4K frames the BASELINE numbers are quoted on (10^8 casts each): every pixel's radiance, depth and sample count
+    bit for bit, cast counters equal."""
+    from conftest import bits, ensure_assets
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h = size
+    c = hip.Context(0)
+    c.upload_scene(load_scene_blob(scene, size=size))
+    assert "qa_integrate_cs" in c.kernel_name()
+    c.reset_counters()
+    a = c.render_region((0, 0, w, h), spp)
+    ca = c.counters()
+    c.reset_counters()
+    b = c.render_region((0, 0, w, h), spp, stats=True)
+    cb = c.counters()
+    c.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(bits(x), bits(y))
+    assert all(ca[k] == cb[k] for k in ("samples", "casts_normal", "casts_shadow", "pixels"))
