@@ -64,6 +64,13 @@ const uint8_t *qa_fb_mask(const qa_fb *fb);
 const uint8_t *qa_fb_z_image(qa_fb *fb);
 const uint8_t *qa_fb_sample_count_image(qa_fb *fb);
 int qa_fb_num_rendered_pixels(const qa_fb *fb);
+/* Multi-GPU placement (the analogue of PlaceImage<T>, src/renderers/Renderer_MPI.cpp:103-122): rank `rank` of `world` owns
+ * the 8-row strips rank, rank + world, ...; its PACKED float results (include/qaray_hip.h qa_render_strips_device) are
+ * deposited into the rows they belong to.  Returns the number of strips placed (negative QA_E* on bad arguments).
+ * qa_strip_row_range: image rows [y0, y1) of packed strip k of that rank; 0 when the rank has no such strip. */
+int qa_fb_place_strips(qa_fb *fb, int world, int rank, const float *rgb, const float *depth, const uint32_t *nsamples,
+                       int spp_max, int use_srgb);
+int qa_strip_row_range(int height, int world, int rank, int k, int *y0, int *y1);
 int qa_fb_save_image(const qa_fb *fb, const char *png_path);
 int qa_fb_save_z_image(qa_fb *fb, const char *png_path);
 int qa_fb_save_sample_count_image(qa_fb *fb, const char *png_path);

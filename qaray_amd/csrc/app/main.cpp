@@ -1,7 +1,8 @@
 // qaray_hip — batch driver with the reference's command line (src/main.cpp:8-62):
 //   qaray_hip [-batch] [-spp N] [-sppMin N] [-sppMax N] [-bounce N] [-srgb 0|1] [-threads N]
 //             [-use-photon-map] [-photon-map-size N] [-caustics-map-size N] scene.xml
-// plus what the reference has no flag for: -size W H, -seed S, -device D, -out PREFIX, -root DIR,
+// plus what the reference has no flag for: -size W H, -seed S, -device D, -devices N (GPUs 0..N-1 of this node in one
+// process: one host thread and one context per GPU, strips gathered on the first; Renderer::UseDevices), -out PREFIX, -root DIR,
 // -photon-map-radius R, -caustics-map-radius R, -photon-map-bounce N, -caustics-map-bounce N.
 // The reference's `-sppMax` sets sppMin by mistake (main.cpp:27-28); here it sets sppMax.
 // Flow: Init -> LoadScene -> ComputeScene -> Render -> Terminate (main.cpp:55-59).
@@ -9,6 +10,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "renderer.h"
 
@@ -20,7 +22,7 @@ int main(int argc, char **argv)
   RendererParam param;
   const char *file = nullptr;
   std::string out, root;
-  int device = 0, w = -1, h = -1;
+  int device = 0, w = -1, h = -1, devices = 0;
   if (argc < 2) { fprintf(stderr, "Error: insufficient input\n"); return -1; }
   for (int i = 1; i < argc; ++i) {
     const std::string s(argv[i]);
@@ -42,6 +44,7 @@ int main(int argc, char **argv)
     else if (s == "-size") { w = atoi(next()); h = atoi(next()); }
     else if (s == "-seed") param.seed = (uint32_t) strtoul(next(), nullptr, 0);
     else if (s == "-device") device = atoi(next());
+    else if (s == "-devices") devices = atoi(next());
     else if (s == "-out") out = next();
     else if (s == "-root") root = next();
     else file = argv[i];
@@ -49,6 +52,11 @@ int main(int argc, char **argv)
   if (!file) { fprintf(stderr, "Error: no scene file\n"); return -1; }
   try {
     Renderer renderer(param, device);
+    if (devices > 0) {
+      std::vector<int> ids;
+      for (int d = 0; d < devices; ++d) ids.push_back(device + d);
+      renderer.UseDevices(ids);
+    }
     renderer.outputPrefix = out;
     renderer.Init();
     Scene scene;

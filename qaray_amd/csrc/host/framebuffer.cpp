@@ -116,6 +116,27 @@ void FrameBuffer::Deposit(int x0, int y0, int x1, int y1, const float *rgb, cons
   IncrementNumRenderPixel((x1 > x0 && y1 > y0) ? cw * (y1 - y0) : 0);
 }
 
+bool StripRowRange(int height, int world, int rank, int k, int &y0, int &y1)
+{
+  if (height <= 0 || world < 1 || rank < 0 || rank >= world || k < 0) return false;
+  const int strip = rank + k * world;
+  y0 = strip * 8;
+  if (y0 >= height) return false;
+  y1 = y0 + 8 < height ? y0 + 8 : height;
+  return true;
+}
+
+int PlaceStrips(FrameBuffer &fb, int width, int height, int world, int rank, const float *rgb, const float *depth, const uint32_t *nsamples, int sppMax,
+                bool useSRGB)
+{
+  int k = 0, y0, y1;
+  for (; StripRowRange(height, world, rank, k, y0, y1); ++k) {
+    const size_t off = (size_t) k * 8 * (size_t) width;
+    fb.Deposit(0, y0, width, y1, rgb + 3 * off, depth + off, nsamples + off, sppMax, useSRGB);
+  }
+  return k;
+}
+
 namespace tasking {
 static std::atomic<bool> threadStop{false};
 static std::atomic<size_t> numThreads{0};   // 0 = not initialised

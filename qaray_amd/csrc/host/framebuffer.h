@@ -55,6 +55,14 @@ class FrameBuffer {
 
 extern FrameBuffer renderImage;  // src/scene/scene.cpp:78
 
+// Image-space partition between GPUs (include/qaray_hip.h qa_render_strips_device): rank r of n owns the 8-row strips
+// r, r + n, ...; its outputs are packed strip after strip.  PlaceStrips is the analogue of PlaceImage<T>
+// (src/renderers/Renderer_MPI.cpp:103-122): rank `rank`'s packed float results go through Deposit into the rows they
+// belong to.  Returns the number of strips placed.  StripRowRange: image rows [y0, y1) of packed strip k (false: no such strip).
+bool StripRowRange(int height, int world, int rank, int k, int &y0, int &y1);
+int PlaceStrips(FrameBuffer &fb, int width, int height, int world, int rank, const float *rgb, const float *depth, const uint32_t *nsamples,
+                int sppMax, bool useSRGB);
+
 // src/tasking/parallel_for.h:59-95, same names and signatures.  The pixel work itself runs on the GPU (one
 // qa_render_* call replaces ThreadRender's two nested parallel_for loops); what stays on the host - one worker per
 // GPU of a node, strip assembly, file output - can still be spread with parallel_for, and every work item polls

@@ -104,6 +104,19 @@ const float *qa_fb_zbuffer(const qa_fb *fb) { return fb ? fb->fb.GetZBuffer() : 
 const uint8_t *qa_fb_sample_count(const qa_fb *fb) { return fb ? fb->fb.GetSampleCount() : nullptr; }
 const uint8_t *qa_fb_mask(const qa_fb *fb) { return fb ? fb->fb.GetMasks() : nullptr; }
 int qa_fb_num_rendered_pixels(const qa_fb *fb) { return fb ? fb->fb.GetNumRenderedPixels() : 0; }
+int qa_fb_place_strips(qa_fb *fb, int world, int rank, const float *rgb, const float *depth, const uint32_t *nsamples, int spp_max, int use_srgb)
+{
+  if (!fb || !rgb || !depth || !nsamples || world < 1 || rank < 0 || rank >= world) return QA_EINVAL;
+  return PlaceStrips(fb->fb, fb->fb.GetWidth(), fb->fb.GetHeight(), world, rank, rgb, depth, nsamples, spp_max, use_srgb != 0);
+}
+int qa_strip_row_range(int height, int world, int rank, int k, int *y0, int *y1)
+{
+  int a = 0, b = 0;
+  const bool ok = StripRowRange(height, world, rank, k, a, b);
+  if (y0) *y0 = a;
+  if (y1) *y1 = b;
+  return ok ? 1 : 0;
+}
 int qa_fb_save_image(const qa_fb *fb, const char *p) { return (fb && p && fb->fb.SaveImage(p)) ? QA_OK : Fail(QA_EIO, "cannot write image"); }
 int qa_fb_save_z_image(qa_fb *fb, const char *p)
 {

@@ -46,6 +46,12 @@ struct RendererParam {  // src/renderers/renderer.h:47-68
 class Renderer {
  public:
   explicit Renderer(RendererParam &param, int device = 0, size_t rank = 0, size_t size = 1);
+  // One process, several GPUs (qaray_hip -devices N): the role Renderer_MPI plays across MPI ranks
+  // (src/renderers/Renderer_MPI.cpp:123-215), inside one address space.  One host thread and one qa_ctx per device; the
+  // flattened scene is uploaded to the first device and copied to the others device-to-device (xGMI); device i renders the
+  // 8-row strips i, i + N, ...; the packed colour | depth | sample-count strips are copied to the first device
+  // (hipMemcpyPeerAsync) and placed from there (PlaceStrips = PlaceImage<T>).  devices.size() == 1 takes the same path.
+  void UseDevices(const std::vector<int> &devices) { multi = devices; }
   virtual ~Renderer();
   virtual void Init();                                  // creates the HIP context
   void ComputeScene(FrameBuffer &renderImage, Scene &scene);  // camera frame, fb, scene upload, photon maps
@@ -67,6 +73,9 @@ class Renderer {
   size_t mpiSize = 1, mpiRank = 0;                      // strip partition: rank, rank+size, ...
   int device = 0;
   qa_ctx *ctx = nullptr;
+  std::vector<int> multi;                               // UseDevices: empty = the single-context path
+  std::vector<qa_ctx *> ctxs;                           // one per entry of `multi`
+  void ThreadRenderMulti();
   double lastSeconds = 0, avgSeconds = 0;
   int numFrames = -1;
   qa_counters counters{};

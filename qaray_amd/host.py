@@ -41,6 +41,8 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = rt
         L.qa_fb_num_rendered_pixels.argtypes = [C.c_void_p]
+        L.qa_fb_place_strips.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.qa_strip_row_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         for name in ("qa_fb_save_image", "qa_fb_save_z_image", "qa_fb_save_sample_count_image"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_char_p]
         L.qa_tasking_init.restype = None
@@ -130,6 +132,17 @@ class FrameBuffer:
         assert rgb.size == 3 * n and depth.size == n and nsamples.size == n
         _check(lib().qa_fb_deposit(self._h, x0, y0, x1, y1, rgb.ctypes.data, depth.ctypes.data,
                                    nsamples.ctypes.data, int(spp_max), int(bool(use_srgb))))
+
+    def place_strips(self, world, rank, rgb, depth, nsamples, spp_max, use_srgb=True):
+        """Deposit rank `rank`'s PACKED strips (8-row strips rank, rank + world, ...) into the rows they belong to -> strips placed."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        nsamples = np.ascontiguousarray(nsamples, dtype=np.uint32)
+        n = lib().qa_fb_place_strips(self._h, int(world), int(rank), rgb.ctypes.data, depth.ctypes.data, nsamples.ctypes.data,
+                                     int(spp_max), int(bool(use_srgb)))
+        if n < 0:
+            raise HostError(n, "qa_fb_place_strips: bad arguments")
+        return n
 
     def _arr(self, fn, shape, dtype):
         p = fn(self._h)

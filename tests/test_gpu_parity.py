@@ -555,3 +555,29 @@ def test_cooperative_kernel_equals_the_reference_walk_at_the_quoted_frame_sizes(
     for x, y in zip(a, b):
         assert np.array_equal(bits(x), bits(y))
     assert all(ca[k] == cb[k] for k in ("samples", "casts_normal", "casts_shadow", "pixels"))
+
+
+@pytest.mark.parametrize("scene,size,spp", [("example_project12_box.xml", (200, 131), 4), ("trc_scene_tower.xml", (160, 90), 2)])
+def test_cli_multi_device_path_equals_the_single_context_path(tmp_path, scene, size, spp):
+    """qaray_hip -devices 1 takes the C++ multi-GPU route (one host thread + context per device, flattened scene copied
+    device-to-device, strips rendered with qa_render_strips_device, peer copy of the packed colour | depth | sample-count
+    buffer to the first device, PlaceStrips) - with the one GPU of this box.  Its three PNGs must equal the classic
+    single-context CLI's byte for byte (131 rows: a ragged last strip)."""
+    import os
+    import subprocess
+    from conftest import ensure_assets
+    from qaray_amd.host import SCENES_DIR
+    ensure_assets()
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "qaray_amd", "lib", "qaray_hip")
+    outs = {}
+    for mode, extra in (("single", []), ("multi", ["-devices", "1"])):
+        out = str(tmp_path / mode) + "_"
+        r = subprocess.run([exe, "-batch", "-spp", str(spp), "-size", str(size[0]), str(size[1]), "-root", SCENES_DIR, "-out", out] + extra +
+                           [os.path.join(SCENES_DIR, scene)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        if mode == "multi":
+            assert "Running on 1 HIP device(s)" in r.stdout
+        outs[mode] = {n: open(out + n, "rb").read() for n in ("colorBuffer.png", "depthBuffer.png", "sampleBuffer.png")}
+        outs[mode]["samples"] = [l for l in r.stdout.splitlines() if l.startswith("samples ")][0].split("  ")[0:2]
+    assert outs["single"] == outs["multi"]

@@ -307,3 +307,39 @@ def test_framebuffer_products_equal_the_references_own(name):
     assert np.array_equal(fb.sample_count_image, z["countimg"])
     assert fb.num_rendered_pixels == w * h and (fb.mask == 1).all()
     fb.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_multi_gpu_strip_placement_equals_the_partition(world):
+    """The C++ multi-device driver's placement (PlaceStrips / StripRowRange, csrc/host/framebuffer.cpp = PlaceImage<T> of
+    src/renderers/Renderer_MPI.cpp:103-122) on the CPU: every rank's PACKED strips land in the rows qaray_amd.distributed
+    assigns to it, every row exactly once, ragged last strip included; a skipped pixel (sample count 0) keeps mask 0."""
+    import ctypes as C
+    from qaray_amd import distributed as qd
+    from qaray_amd import host
+    W, H, spp = 11, 45, 4
+    rng = np.random.default_rng(world)
+    full_rgb = rng.random((H, W, 3), dtype=np.float32)
+    full_z = rng.random((H, W), dtype=np.float32) + 1
+    full_ns = np.full((H, W), spp, np.uint32)
+    full_ns[7, 3] = 0                      # skipped by a stop request
+    ref = FrameBuffer(W, H)
+    ref.deposit(0, 0, W, H, full_rgb, full_z, full_ns, spp, use_srgb=True)
+    fb = FrameBuffer(W, H)
+    rows = qd.max_strips_per_rank(H, world) * qd.STRIP_ROWS
+    placed = 0
+    for rank in range(world):
+        own = qd.own_strips(H, world, rank)
+        p_rgb = np.zeros((rows, W, 3), np.float32); p_z = np.zeros((rows, W), np.float32); p_ns = np.zeros((rows, W), np.uint32)
+        for k, s in enumerate(own):
+            y0, y1 = s * 8, min(H, s * 8 + 8)
+            p_rgb[k * 8:k * 8 + y1 - y0] = full_rgb[y0:y1]; p_z[k * 8:k * 8 + y1 - y0] = full_z[y0:y1]; p_ns[k * 8:k * 8 + y1 - y0] = full_ns[y0:y1]
+            a, b = C.c_int(), C.c_int()
+            assert host.lib().qa_strip_row_range(H, world, rank, k, C.byref(a), C.byref(b)) == 1 and (a.value, b.value) == (y0, y1)
+        assert host.lib().qa_strip_row_range(H, world, rank, len(own), None, None) == 0
+        placed += fb.place_strips(world, rank, p_rgb, p_z, p_ns, spp)
+    assert placed == qd.num_strips(H)
+    assert np.array_equal(fb.pixels, ref.pixels) and np.array_equal(fb.zbuffer, ref.zbuffer)
+    assert np.array_equal(fb.sample_count, ref.sample_count) and np.array_equal(fb.mask, ref.mask)
+    assert fb.mask[7, 3] == 0 and fb.mask.sum() == W * H - 1 and fb.num_rendered_pixels == W * H
+    fb.close(); ref.close()
