@@ -112,6 +112,39 @@ def committed_traffic(kernel_name, scene, W, H, spp):
     return best
 
 
+def committed_sq(scene, W, H, spp):
+    """Compute-side counters of the same frame (rocprofv3 SQ passes summarised by tools/sq_summary.py under profiles/)."""
+    best = None
+    try:
+        prof_dir = os.path.join(ROOT, "profiles")
+        for d in sorted(os.listdir(prof_dir)):
+            for f in sorted(os.listdir(os.path.join(prof_dir, d))):
+                if f.endswith("_sq_counters.json"):
+                    sj = json.load(open(os.path.join(prof_dir, d, f)))
+                    if sj.get("frame") == [W, H] and sj.get("spp") == spp and sj.get("scene") == scene and "derived" in sj:
+                        best = (sj, os.path.join("profiles", d, f))
+    except Exception:
+        pass
+    return best
+
+
+def add_compute_side(roof, scene, W, H, spp):
+    """valu_issue_frac = vector wave-instructions x 2 cycles / SIMD-cycles (a wave64 instruction issues over 2 cycles on a
+    SIMD-32), x lane utilisation = the useful share of the vector issue bandwidth; 'bound' says what the counters say."""
+    sq = committed_sq(scene, W, H, spp)
+    if not sq:
+        return
+    dv = sq[0]["derived"]
+    for k in ("valu_issue_frac", "valu_lane_utilisation", "valu_useful_frac", "wave_time_issuing", "wave_time_issue_stalled", "wave_time_waiting"):
+        if k in dv:
+            roof[k] = dv[k]
+    roof["sq_source"] = sq[1] + " (kernel " + str(sq[0].get("kernel", "?"))[:60] + ")"
+    if dv.get("valu_issue_frac", 0) + 0.0 >= 0.45:
+        roof["bound"] = "valu-issue"   # half of the vector issue slots taken, a third of wave time stalled on issue: not HBM
+    else:
+        roof["bound"] = "latency"      # waves mostly wait (dependent loads, LDS round trips): neither HBM bandwidth nor vector issue
+
+
 CPU_SAMPLE_SPP = {"c3": 24, "c4": 10, "c5": 6}   # bounded CPU samples of >= 5 s on 16 host threads (4.1 / 13.1 / 7.3 Msamples/s in round 2)
 
 
@@ -151,6 +184,7 @@ def other_config(ctx, tag, args, torch, hip, qd, load_scene_blob, SCENES_DIR, de
     if best:
         out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
         out["roofline"]["traffic_source"] = best[1]
+    add_compute_side(out["roofline"], cfg["scene"], W, H, spp)
     if args.cpu_spp > 0:
         out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, CPU_SAMPLE_SPP[tag], args.seed)
     return out
@@ -342,6 +376,8 @@ def main():
             # duration (HIP events on the launch stream).  That is the contract's figure; it is NOT memory traffic: the
             # megakernel keeps path state in registers, and neither integrator is bound by HBM bandwidth or by its arithmetic
             # (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt): see 'actual_limiter'.
+            # 'bound': "hbm" is what SURVEY 8(d) prices (and 'frac' is that figure); where SQ counter passes of this frame are
+            # committed, add_compute_side() replaces it by what the counters say and adds the vector-issue fractions.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": kernel_name, "kernel_ms_avg": k_ms, "launches": int(launches),
@@ -362,6 +398,8 @@ def main():
             out["roofline"]["measured_hbm_gbs"] = best[0]["hbm_traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
             out["roofline"]["traffic_source"] = (best[1] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, separate --pmc passes: an UPPER bound for HBM, "
                                                  "the counters also see Infinity-Cache hits; measured on build " + str(best[0].get("build", "?")) + ")")
+        if world == 1:
+            add_compute_side(out["roofline"], os.path.basename(scene_xml), W, H, args.spp)
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, args.cpu_spp, args.seed)
         # the default one-GPU line also carries ONE full-spp step of BASELINE's other three configs (the driver only runs this command)

@@ -45,6 +45,16 @@ namespace qa {
 #define QA_BIAS 0.005f         /* src/objects/objects.cpp:19 */
 #define QA_DX 0.01f            /* DiffRay::dx = dy, src/core/ray.cpp:31-32 */
 #define QA_DONE 0xFFFFFFFFu    /* traversal sentinel (has the leaf bit set, never a real node word) */
+// qa_integrate's DCounters are per LANE, reduced by shuffles at the end.  (-DQA_WAVE_TALLIES: the lanes that reach a tally add
+// their number to a wave-uniform count in scalar registers instead - eight vector registers less on paper; measured on the
+// Cornell-box kernel: 101 instead of 87 spilled registers and 12.4 instead of 13.1 Gsamples/s, profiles/round03/experiments.txt.
+// qa_integrate_cs does tally per wave.)
+#ifdef QA_WAVE_TALLIES
+#define QA_TALLY(x) (x) += (unsigned long long) __popcll(__ballot(1))
+#else
+#define QA_LANE_TALLIES 1
+#define QA_TALLY(x) (x)++
+#endif
 
 #ifdef QA_STAMPS
 #define QA_T(var) const unsigned long long var = __builtin_readcyclecounter();
@@ -540,7 +550,7 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
   while (cur != QA_DONE) {
     // ---- descend inner nodes until this lane holds a leaf (or runs out of work) --------------
     while (!(cur & QA_BVH_LEAF_BIT)) {
-      if (STATS) cnt.bvh_nodes++;
+      if (STATS) QA_TALLY(cnt.bvh_nodes);
       const uint4 *pair = nodes + 2 * (size_t) (cur & QA_BVH_CHILD_MASK);
       const uint4 a0 = ld16<GMEM>(pair), a1 = ld16<GMEM>(pair + 1), b0 = ld16<GMEM>(pair + 2), b1 = ld16<GMEM>(pair + 3);
       float entry0, exit0, entry1, exit1;
@@ -576,11 +586,11 @@ __device__ __forceinline__ bool walkBVH(const uint4 *nodes, const uint4 *tris, u
     }
     if (cur == QA_DONE) break;
     // ---- leaf: its triangles in element order -----------------------------------------------
-    if (STATS) cnt.bvh_nodes++;
+    if (STATS) QA_TALLY(cnt.bvh_nodes);
     const uint32_t count = ((cur >> QA_BVH_COUNT_SHIFT) & QA_BVH_COUNT_MASK) + 1;
     const uint32_t first = cur & QA_BVH_OFFSET_MASK;
     for (uint32_t i = 0; i < count; ++i) {
-      if (STATS) cnt.tri_tests++;
+      if (STATS) QA_TALLY(cnt.tri_tests);
       const uint4 *t = tris + 3 * (size_t) (first + i);
       const uint4 t2 = ld16<GMEM>(t + 2);
       bool accepted;
@@ -859,7 +869,7 @@ template <bool RES, bool TEX, bool STATS>
 __device__ __forceinline__ bool traceClosest(const SceneMem<RES> mem, const DScene &sc, const Ray &world, const RayDiff &wd,
                                              Hit &h, TexHit &th, uint32_t *stack, DCounters &cnt)
 {
-  cnt.casts_normal++;
+  QA_TALLY(cnt.casts_normal);
   const Ray r0 = rootRay<RES>(sc, world);
   GroupRay grp;
   grp.node = -1;
@@ -914,7 +924,7 @@ template <bool RES, bool STATS>
 __device__ __forceinline__ float shadow(const SceneMem<RES> mem, const DScene &sc, const Ray &world, float t_max,
                                         uint32_t *stack, DCounters &cnt)
 {
-  cnt.casts_shadow++;
+  QA_TALLY(cnt.casts_shadow);
   Hit h;
   h.z = t_max;
   h.node = -1;
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       path.primary = true;
       needSample = false;
       nrec = 0;
-      cnt.samples++;
+      QA_TALLY(cnt.samples);
     }
 
     QA_TACC(cnt.sl[1], tA)
@@ -1485,7 +1495,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
         rp.ns[q] = (uint32_t) sidx;
-        cnt.pixels++;
+        QA_TALLY(cnt.pixels);
         needPixel = true;
       }
     }
@@ -1497,7 +1507,9 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(rp.counters);
   for (int i = 0; i < 6; ++i) {
     unsigned long long x = v[i];
+#ifdef QA_LANE_TALLIES
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+#endif
     if (lane == 0 && x) atomicAdd(&dst[i], x);
   }
 #ifdef QA_STAMPS

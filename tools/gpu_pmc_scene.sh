@@ -7,7 +7,7 @@ mkdir -p $OUT
 python3 $R/scenes/gen_assets.py > /dev/null
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1 --warmup 0 --cpu-spp 0 --spp ${SPP:-8} --scene ${SCENE:-trc_scene_tower.xml}"
+ARGS="--no-other-configs --steps 1 --warmup 0 --cpu-spp 0 --spp ${SPP:-8} --scene ${SCENE:-trc_scene_tower.xml}"
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS" \
