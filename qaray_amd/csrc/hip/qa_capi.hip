@@ -94,11 +94,18 @@ static int SelectKernel(qa_ctx *c)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
   // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
-  // (any number of lights: their shadow queries are pooled four lights at a time, qa_kernel_cs.h csDirectLight)
+  // (at most QA_CS_LIGHT_BATCH = 4 non-ambient lights: their unshadowed terms are kept in registers while the wave sweeps the
+  // scene for the shadow rays, qa_kernel_cs.h csLightTerms; scenes with more lights keep qa_integrate)
   c->kernelCs = nullptr;
   {
     const char *e = DevEnv("QA_COOP");
-    if (!c->resident && !c->area && c->csFits && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
+    int shadowLights = 0;
+    {
+      const qa_flat_header *fh = reinterpret_cast<const qa_flat_header *>(c->hostBlob.data());
+      const qa_light *hl = QA_BLOB_PTR(qa_light, c->hostBlob.data(), fh->off_lights);
+      for (uint32_t i = 0; i < fh->num_lights; ++i) shadowLights += hl[i].type != QA_LIGHT_AMBIENT;
+    }
+    if (!c->resident && !c->area && c->csFits && shadowLights <= QA_CS_LIGHT_BATCH && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
       c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true> : (KernelFn) qa_integrate_cs<true, false>)
                            : (c->textured ? (KernelFn) qa_integrate_cs<false, true> : (KernelFn) qa_integrate_cs<false, false>);
       int n = 0;

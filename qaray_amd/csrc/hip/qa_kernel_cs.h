@@ -472,63 +472,61 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
   grp.node = -1;
   grp.ray = r0;
   QA_T(tSweep)
-  for (int k = 1; k <= sc.num_inst; ++k) {
-    const bool last = k == sc.num_inst;
-    bool coop = false;
-    Ray r;
-    r.p = r.d = F3(0, 0, 0);
-    float pad = 0.f;
-    uint32_t rootWord = 0;
-    if (!last) {
-      const CsInst ci = ldTable(sc.csInst + k);
-      const int type = ci.type;
-      if (type == QA_OBJ_NONE) continue;
-      r = csLocalSweep(ci, r0, grp);
-      if (type != QA_OBJ_MESH) {
-        Hit hh;
-        hh.z = bestZ;
-        hh.node = -1;
-        hh.p = hh.N = F3(0, 0, 0);
-        hh.front = true;
-        const bool hit = act && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, !TEX) : hitPlane(r, hh, k, !TEX));
-        if (hit) {
-          bestZ = hh.z;
-          bestK = k;
-          if (!TEX) {
-            spP = hh.p;
-            spN = hh.N;
-            spFront = hh.front;
-          }
+  // the walks prune against what the spheres and planes have already settled
+#define QA_CS_SETTLE_SOLIDS                                                                                                     \
+  if (bestK >= 0) {                                                                                                             \
+    unsigned long long *key = csKeys(L) + lane;                                                                                 \
+    const unsigned long long mine = ((unsigned long long) __float_as_uint(bestZ) << 32) | 0xFFFFFFFFull, old = *key;            \
+    if ((uint32_t) (old >> 32) == __float_as_uint(bestZ) && old != mine) L.flags[lane] = 1; /* a triangle at exactly that distance: order decides */ \
+    if (mine < old) *key = mine;                                                                                                \
+  }
+  for (int k = 1; k < sc.num_inst; ++k) {
+    const CsInst ci = ldTable(sc.csInst + k);
+    const int type = ci.type;
+    if (type == QA_OBJ_NONE) continue;
+    const Ray r = csLocalSweep(ci, r0, grp);
+    if (type != QA_OBJ_MESH) {
+      Hit hh;
+      hh.z = bestZ;
+      hh.node = -1;
+      hh.p = hh.N = F3(0, 0, 0);
+      hh.front = true;
+      const bool hit = act && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, !TEX) : hitPlane(r, hh, k, !TEX));
+      if (hit) {
+        bestZ = hh.z;
+        bestK = k;
+        if (!TEX) {
+          spP = hh.p;
+          spN = hh.N;
+          spFront = hh.front;
         }
-        continue;
       }
-      // (gate against the spheres and planes met so far: any limit not below the final answer is safe, and a triangle at
-      // exactly the distance held raises the flag whatever the gate saw)
-      const bool go = act && csGate(ci, r, bestZ);
-      coop = go && ci.useWide && insideCancelReach(ci, r.p);
-      exact = exact || (go && !coop);
-      pad = csPad(ci, r.p);
-      rootWord = ci.csRootWord;
+      continue;
     }
+    // (gate against the spheres and planes met so far: any limit not below the final answer is safe, and a triangle at
+    // exactly the distance held raises the flag whatever the gate saw)
+    const bool go = act && csGate(ci, r, bestZ);
+    const bool coop = go && ci.useWide && insideCancelReach(ci, r.p);
+    exact = exact || (go && !coop);
     const unsigned long long mk = __ballot(coop);
     const uint32_t c = (uint32_t) __popcll(mk);
-    if (last ? n != 0 : (c != 0 && (nSlots + c > L.slots || n + c > L.capItems))) {
-      // the walks prune against what the spheres and planes have already settled
-      if (bestK >= 0) {
-        unsigned long long *key = csKeys(L) + lane;
-        const unsigned long long mine = ((unsigned long long) __float_as_uint(bestZ) << 32) | 0xFFFFFFFFull, old = *key;
-        if ((uint32_t) (old >> 32) == __float_as_uint(bestZ) && old != mine) L.flags[lane] = 1;   // a triangle at exactly that distance: order decides
-        if (mine < old) *key = mine;
-      }
+    if (!c) continue;
+    // The pool runs when it cannot take this instance's rays - rarely: the run that matters is the one after the sweep, where
+    // nothing of the sweep is alive any more (the branch weight keeps the allocator's spill code out of the common path)
+    if (__builtin_expect(nSlots + c > L.slots || n + c > L.capItems, 0)) {
+      QA_CS_SETTLE_SOLIDS
       csRun<true>(sc, L, n, QA_FILL(cnt));
       nSlots = 0;
     }
-    if (c) {
-      csEnter(L, mk, coop, r, 0.f, (uint32_t) k, pad, rootWord, n, nSlots);
-      n += c;
-      nSlots += c;
-    }
+    csEnter(L, mk, coop, r, 0.f, (uint32_t) k, csPad(ci, r.p), ci.csRootWord, n, nSlots);
+    n += c;
+    nSlots += c;
   }
+  if (n != 0) {
+    QA_CS_SETTLE_SOLIDS
+    csRun<true>(sc, L, n, QA_FILL(cnt));
+  }
+#undef QA_CS_SETTLE_SOLIDS
   QA_TACC(cnt.sl[13], tSweep)
   QA_T(tDet)
   uint32_t elem;
@@ -703,52 +701,35 @@ __device__ __forceinline__ void csShadowRay(const qa_light &l, f3 p, Ray &w, flo
 // GenLight::Shadow -> Scene::TraceNodeShadow for the next batch of up to QA_CS_LIGHT_BATCH non-ambient lights (table index li
 // onwards; on return li is where the following batch starts and nb the lights taken), for the lanes with `lit`: bit jj of the
 // result = light jj of the batch occluded.  The reference stops at the first node that occludes; which one does not matter.
-// One loop over (light, instance) pairs with ONE place where the pool runs: when it is full, and after the last pair.
+// The pool runs once, after the sweeps of all the batch's lights (and, rarely, in between when it cannot take an instance's rays).
 __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds &L, bool lit, f3 p, int &li, uint32_t &nb, DCounters &cnt)
 {
   const unsigned lane = __lane_id();
   uint32_t occl = 0, redo = 0;
   for (uint32_t jj = 0; jj < QA_CS_LIGHT_BATCH; ++jj) L.res[jj * 64u + lane] = 0;
   L.flags[lane] = 0;
-  uint32_t n = 0, nSlots = 0, jj = 0;
+  uint32_t n = 0, nSlots = 0;
   nb = 0;
-  bool last = false;
-  int k = sc.num_inst;   // (the first iteration fetches a light)
-  Ray w, r0;
-  w.p = w.d = r0.p = r0.d = F3(0, 0, 0);
-  float tmax = 0.f;
-  GroupRay grp;
-  grp.node = -1;
-  grp.ray = r0;
   QA_T(tSweep)
-  for (;;) {
-    ++k;
-    if (k >= sc.num_inst) {
-      while (li < sc.num_lights && ldTable(sc.light + li).type == QA_LIGHT_AMBIENT) ++li;
-      if (li >= sc.num_lights || nb == QA_CS_LIGHT_BATCH) last = true;
-      else {
-        const qa_light l = ldTable(sc.light + li);
-        ++li;
-        jj = nb++;
-        csShadowRay(l, p, w, tmax);
-        cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
-        r0 = rootRay<false>(sc, w);
-        grp.node = -1;
-        k = 1;
-      }
-    }
-    bool coop = false;
-    Ray r;
-    r.p = r.d = F3(0, 0, 0);
-    float pad = 0.f;
-    uint32_t rootWord = 0;
-    if (!last) {
+  for (; li < sc.num_lights && nb < QA_CS_LIGHT_BATCH; ++li) {
+    const qa_light l = ldTable(sc.light + li);
+    if (l.type == QA_LIGHT_AMBIENT) continue;
+    const uint32_t jj = nb++;
+    Ray w;
+    float tmax;
+    csShadowRay(l, p, w, tmax);
+    cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
+    const Ray r0 = rootRay<false>(sc, w);
+    GroupRay grp;
+    grp.node = -1;
+    grp.ray = r0;
+    for (int k = 1; k < sc.num_inst; ++k) {
       const bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
-      if (!__any(open)) { k = sc.num_inst; continue; }          // settled for the whole wave: next light
+      if (!__any(open)) break;                                   // settled for the whole wave: next light
       const CsInst ci = ldTable(sc.csInst + k);
       const int type = ci.type;
       if (type == QA_OBJ_NONE) continue;
-      r = csLocalSweep(ci, r0, grp);
+      const Ray r = csLocalSweep(ci, r0, grp);
       if (type != QA_OBJ_MESH) {
         Hit hh;
         hh.z = tmax;
@@ -758,27 +739,29 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
         continue;
       }
       const bool go = open && csGate(ci, r, tmax);
-      coop = go && ci.useWide && insideCancelReach(ci, r.p);
+      bool coop = go && ci.useWide && insideCancelReach(ci, r.p);
       if (go && !coop) redo |= 1u << jj;
-      pad = csPad(ci, r.p);
-      rootWord = ci.csRootWord;
-    }
-    unsigned long long mk = __ballot(coop);
-    uint32_t c = (uint32_t) __popcll(mk);
-    if (last ? n != 0 : (c != 0 && (nSlots + c > L.slots || n + c > L.capItems))) {
-      csRun<false>(sc, L, n, QA_FILL(cnt));
-      csSettleShadows(sc, L, nb, occl, redo);   // before the slots are reused
-      nSlots = 0;
-      coop = coop && !(((occl | redo) >> jj) & 1u);   // queries that run decided do not enter
-      mk = __ballot(coop);
-      c = (uint32_t) __popcll(mk);
-    }
-    if (last) break;
-    if (c) {
-      csEnter(L, mk, coop, r, tmax, jj, pad, rootWord, n, nSlots);
+      unsigned long long mk = __ballot(coop);
+      uint32_t c = (uint32_t) __popcll(mk);
+      if (!c) continue;
+      // (rarely: see csTraceClosest)
+      if (__builtin_expect(nSlots + c > L.slots || n + c > L.capItems, 0)) {
+        csRun<false>(sc, L, n, QA_FILL(cnt));
+        csSettleShadows(sc, L, nb, occl, redo);   // before the slots are reused
+        nSlots = 0;
+        coop = coop && !(((occl | redo) >> jj) & 1u);   // queries that run decided do not enter
+        mk = __ballot(coop);
+        c = (uint32_t) __popcll(mk);
+        if (!c) continue;
+      }
+      csEnter(L, mk, coop, r, tmax, jj, csPad(ci, r.p), ci.csRootWord, n, nSlots);
       n += c;
       nSlots += c;
     }
+  }
+  if (n != 0) {
+    csRun<false>(sc, L, n, QA_FILL(cnt));
+    csSettleShadows(sc, L, nb, occl, redo);
   }
   QA_TACC(cnt.sl[17], tSweep)
   // ---- the exact repeats
@@ -823,24 +806,40 @@ __device__ __forceinline__ f3 csLightTerm(const qa_light &l, float normCoefDI, f
   return (intensity * cosNL) * brdf;
 }
 
-// Direct lighting of the lanes with `lit` (MtlBlinn_PhotonMap.cpp:481-498): every non-ambient light in table order, the
-// shadow queries of up to QA_CS_LIGHT_BATCH lights walked together.
-__device__ __forceinline__ f3 csDirectLight(const DScene &sc, const CsLds &L, bool lit, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss, DCounters &cnt)
+// Direct lighting in two halves around the shadow queries (MtlBlinn_PhotonMap.cpp:481-498).  csLightTerms evaluates, BEFORE the
+// shadow queries, every non-ambient light's term as if unshadowed (a shadow factor of 1.0f multiplies exactly); csLightSum adds
+// them in table order afterwards, an occluded light's term times 0.0f (the reference's term with the factor 0.0f is a zero of
+// some sign - or a NaN exactly when the unshadowed term is not finite - and so is this product; a sum that started from +0
+// does not see the sign of a zero).  That way the surface (normal, view direction, the sampled colours, the glossiness: 13
+// values) is dead while the wave sweeps the scene for its shadow rays, and only three values per light are kept.  At most
+// QA_CS_LIGHT_BATCH non-ambient lights (SelectKernel, qa_capi.hip: scenes with more keep qa_integrate).
+struct CsTerms { f3 c0, c1, c2, c3; };
+__device__ __forceinline__ CsTerms csLightTerms(const DScene &sc, bool lit, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss)
+{
+  CsTerms t;
+  t.c0 = t.c1 = t.c2 = t.c3 = F3(0, 0, 0);
+  const float normCoefDI = 1.f / (float) sc.num_lights;
+  uint32_t j = 0;
+  for (int li = 0; li < sc.num_lights && j < QA_CS_LIGHT_BATCH; ++li) {
+    const qa_light l = ldTable(sc.light + li);
+    if (l.type == QA_LIGHT_AMBIENT) continue;
+    f3 c = F3(0, 0, 0);
+    if (lit) c = csLightTerm(l, normCoefDI, p, N, V, kd, ks, gloss, false);
+    if (j == 0) t.c0 = c;
+    else if (j == 1) t.c1 = c;
+    else if (j == 2) t.c2 = c;
+    else t.c3 = c;
+    ++j;
+  }
+  return t;
+}
+__device__ __forceinline__ f3 csLightSum(const CsTerms &t, uint32_t nb, uint32_t occl)
 {
   f3 sum = F3(0, 0, 0);
-  const float normCoefDI = 1.f / (float) sc.num_lights;
-  int li = 0;
-  while (li < sc.num_lights) {
-    int lj = li;
-    uint32_t nb = 0;
-    const uint32_t occl = csShadowBatch(sc, L, lit, p, li, nb, cnt);
-    if (!nb) break;
-    for (uint32_t jj = 0; jj < nb; ++jj, ++lj) {
-      while (ldTable(sc.light + lj).type == QA_LIGHT_AMBIENT) ++lj;
-      const qa_light l = ldTable(sc.light + lj);
-      if (lit) sum = sum + csLightTerm(l, normCoefDI, p, N, V, kd, ks, gloss, (occl >> jj) & 1u);
-    }
-  }
+  if (nb > 0) sum = sum + ((occl & 1u) ? t.c0 * 0.0f : t.c0);
+  if (nb > 1) sum = sum + ((occl & 2u) ? t.c1 * 0.0f : t.c1);
+  if (nb > 2) sum = sum + ((occl & 4u) ? t.c2 * 0.0f : t.c2);
+  if (nb > 3) sum = sum + ((occl & 8u) ? t.c3 * 0.0f : t.c3);
   return sum;
 }
 
@@ -858,32 +857,6 @@ __device__ __forceinline__ f3 csDirectLight(const DScene &sc, const CsLds &L, bo
 #define QA_CS_WAVES_TEX 4
 #endif
 __host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) { return items + 8u * slots + QA_CS_RES_WORDS + 64u + QA_LANE_SLOTS * 64u; }
-
-// shadeSurface (qa_kernel.h) OUT OF LINE.  Shading is where the register pressure peaks (table-driven powf / expf, the 32-tap
-// texture filter, the rejection loops of the glossy lobes); inlined into the kernel, the allocator answers those peaks by
-// keeping long-lived values of the WHOLE loop in scratch and reloading them inside the sweeps and rounds, where every reload is
-// a vector-memory round trip on the critical path.  As a function of its own it is allocated on its own; the kernel pays one
-// save / restore of its live registers per call instead.
-#ifndef QA_CS_SHADE_CALL
-#define QA_CS_SHADE_CALL(TEX) (!(TEX))   /* out of line for the untextured variants (A/B below) */
-#endif
-struct CsMtlTex { const int32_t *mtlTex; };
-template <bool TEX>
-__device__ __attribute__((noinline)) void csShade(const uint4 *mtlTable, const int32_t *mtlTex, const unsigned char *blob, const qa_texmap *texmap, const qa_texture *tex,
-                                                  const float *filter, int mi, f3 N, f3 V, bool front, TexHit th, int bounceLeft, bool fromDiffuse, uint32_t *rng,
-                                                  Surface *out)
-{
-  TexTables tt;
-  tt.blob = blob;
-  tt.texmap = texmap;
-  tt.tex = tex;
-  tt.filter = filter;
-  CsMtlTex mt;
-  mt.mtlTex = mtlTex;
-  uint32_t r = *rng;
-  *out = shadeSurface<TEX, CsMtlTex>(mtlTable, mt, tt, mi, N, V, front, th, bounceLeft, fromDiffuse, r);
-  *rng = r;
-}
 
 // What a path keeps between its segments besides its ray, throughput and radiance, in one word: bounceCount the next hit is
 // shaded with | hInfo.c.hasDiffuseHit of the next hit | camera ray | 1 + the material the ray was spawned from (its absorption
@@ -1055,35 +1028,50 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           V = -ray.d;
           N = h.N;
           p = h.p;
-          if (QA_CS_SHADE_CALL(TEX))
-            csShade<TEX>(mtlTable, sc.mtlTex, tt.blob, tt.texmap, tt.tex, tt.filter, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, &rng, &sf);
-          else
-            sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, rng);
+          // (shadeSurface inline: as a function of its own - tried for the untextured variants - its results come back through
+          // memory or a block of registers that the caller spills: C4 3 790 vs 4 510, C5 1 590 vs 1 690 Msamples/s at 16 spp)
+          sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, rng);
           pL = pL + pT * sf.emission;
           lit = true;
         }
       }
     }
     QA_TACC(cnt.sl[4], tD)
-    // ---- direct lighting: the whole wave walks the shadow rays of its lit lanes
+    // ---- direct lighting, first half: the lights' terms as if unshadowed; then the path moves on to its next segment (or
+    // ends) BEFORE the shadow queries, so that the surface is dead while the wave sweeps the scene for them: what is kept is
+    // the shading point (= the next ray's origin), the throughput the lights are weighted with, and three values per light
+    QA_T(tE)
+    CsTerms terms;
+    terms.c0 = terms.c1 = terms.c2 = terms.c3 = F3(0, 0, 0);
+    f3 litT = F3(0, 0, 0);
     if (LIGHTS) {
       if (__any(lit)) {
-        QA_T(tL)
-        const f3 dl = csDirectLight(sc, L, lit, p, N, V, sf.kd, sf.ks, sf.gloss, cnt);
-        if (lit) pL = pL + pT * dl;
-        QA_TACC(cnt.sl[5], tL)
+        QA_T(tLt)
+        terms = csLightTerms(sc, lit, p, N, V, sf.kd, sf.ks, sf.gloss);
+        QA_TACC(cnt.sl[18], tLt)
       }
     }
-    QA_T(tE)
     if (lit) {
+      litT = pT;
+      ray.p = p;
       if (sf.spawn) {
         // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
-        ray.p = p;
         ray.d = normalize(sf.nextDir);
         pT = pT * sf.bxdf;
         pst = (uint32_t) ((QA_PST_BOUNCE(pst) - 1) & 0xFF) | (sf.nextFromDiffuse ? QA_PST_FROM_DIFFUSE : 0u) | ((uint32_t) (mi + 1) << 16);
       } else {
         done = true;
+      }
+    }
+    // ---- second half: the whole wave walks the shadow rays of its lit lanes
+    if (LIGHTS) {
+      if (__any(lit)) {
+        QA_T(tL)
+        int li = 0;
+        uint32_t nb = 0;
+        const uint32_t occl = csShadowBatch(sc, L, lit, ray.p, li, nb, cnt);
+        if (lit) pL = pL + litT * csLightSum(terms, nb, occl);
+        QA_TACC(cnt.sl[5], tL)
       }
     }
 
