@@ -152,6 +152,10 @@ int qa_set_pipeline(qa_ctx *ctx, int mode);
 /* Options an embedding application or a test may set (the product library reads no environment variable of its own;
  * the developer knobs of the A/B scripts exist only in builds made with -DQA_DEV_KNOBS):
  *   "coop"           1 (default) / 0: cooperative mesh walks where the scene allows them; 0 = every lane walks its own ray
+ *   "cs_cull"        1 (default) / 0: the cooperative kernel skips scene-graph nodes whose bounds a wave's rays all miss; 0 = every
+ *                    node is visited as the reference does (same bits either way: A/B tests)
+ *   "cs_force_exact" tests: bit 0 / bit 1 send every closest-hit / shadow query of the cooperative kernel to its exact sequential
+ *                    walks (the path a tie, a failed order check or a full pool takes); same bits, much slower
  *   "cs_pool_limit"  n > 0: upper bound for the pool of the cooperative walks (tests: forces the overflow path); 0 = none
  *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together
  *   "tile_order"     1 (default) / 0: tiles handed out centre-first

@@ -65,7 +65,7 @@ static const char *kStagedName = "staged: wf_logic + wf_cull + wf_trace + wf_red
 static std::string MegaName(const qa_ctx *c, bool cs)
 {
   char name[160];
-  if (cs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d>", (int) (c->ds.num_lights > 0), (int) c->textured);
+  if (cs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d,CULL=%d>", (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->csCullVariant);
   else snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->area);
   return name;
 }
@@ -106,8 +106,15 @@ static int SelectKernel(qa_ctx *c)
       for (uint32_t i = 0; i < fh->num_lights; ++i) shadowLights += hl[i].type != QA_LIGHT_AMBIENT;
     }
     if (!c->resident && !c->area && c->csFits && shadowLights <= QA_CS_LIGHT_BATCH && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
-      c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true> : (KernelFn) qa_integrate_cs<true, false>)
-                           : (c->textured ? (KernelFn) qa_integrate_cs<false, true> : (KernelFn) qa_integrate_cs<false, false>);
+      // instance culling (qa_kernel_cs.h): the textured variants always (it pays from a handful of nodes on: C3, 9 nodes, + 4 %), the
+      // untextured ones on scenes of more than 12 nodes (their register budget: see the kernel's comment)
+      c->csCullVariant = c->csCullOk && (c->textured || c->ds.num_inst > 12);
+      if (c->csCullVariant)
+        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, true> : (KernelFn) qa_integrate_cs<true, false, true>)
+                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, true> : (KernelFn) qa_integrate_cs<false, false, true>);
+      else
+        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, false> : (KernelFn) qa_integrate_cs<true, false, false>)
+                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, false> : (KernelFn) qa_integrate_cs<false, false, false>);
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytesCs) != hipSuccess || n < 1) n = 2;
       c->blocksPerCUCs = n > 8 ? 8 : n;
@@ -609,6 +616,10 @@ static int PrepareScene(qa_ctx *c)
     if (!(memcmp(inst[0].tm, I9, 36) == 0 && memcmp(inst[0].itm, I9, 36) == 0 && memcmp(inst[0].pos, Z3, 12) == 0)) csFits = false;   // (XML scenes: always the identity)
     std::vector<CsInst> ci(h->num_instances);
     memset(ci.data(), 0, ci.size() * sizeof(CsInst));
+    std::vector<CsCull> cull(h->num_instances);
+    for (CsCull &cb : cull) { cb.lo[0] = cb.lo[1] = cb.lo[2] = 3e38f; cb.hi[0] = cb.hi[1] = cb.hi[2] = -3e38f; cb.pad0 = cb.pad1 = 0.f; }   // empty: never entered
+    double cullS1 = 1, cullS2 = 1, cullK3 = 0, cullK4 = 0;
+    bool cullOk = true;
     for (uint32_t k = 1; k < h->num_instances; ++k) {
       const qa_instance &in = inst[k];
       CsInst &r = ci[k];
@@ -645,7 +656,32 @@ static int PrepareScene(qa_ctx *c)
         for (int q = 0; q < 3; ++q) { wlo[q] = std::min(wlo[q], pnt[q]); whi[q] = std::max(whi[q], pnt[q]); }
       }
       for (int q = 0; q < 3; ++q) { r.wmin[q] = (float) wlo[q]; r.wmax[q] = (float) whi[q]; }
+      // instance culling (qa_kernel_cs.h csCullRay): bounds rounded outwards, and this node's share of the scene's widening constants
+      CsCull &cb = cull[k];
+      double boxAbs = 0;
+      for (int q = 0; q < 3; ++q) {
+        cb.lo[q] = std::nextafterf((float) wlo[q], -INFINITY);
+        cb.hi[q] = std::nextafterf((float) whi[q], INFINITY);
+        boxAbs = std::max({boxAbs, std::fabs(wlo[q]), std::fabs(whi[q])});
+      }
+      auto normInf = [](const float *m) { double n = 0; for (int rr = 0; rr < 3; ++rr) n = std::max(n, (double) std::fabs(m[rr]) + std::fabs(m[3 + rr]) + std::fabs(m[6 + rr])); return n; };
+      auto vecInf = [](const float *v) { return std::max({(double) std::fabs(v[0]), (double) std::fabs(v[1]), (double) std::fabs(v[2])}); };
+      double cond = normInf(a.tm) * normInf(a.itm), tmNorm = normInf(a.tm), posAbs = vecInf(a.pos);
+      if (in.depth == 2) {
+        cond *= normInf(in.tm) * normInf(in.itm);
+        posAbs += normInf(a.tm) * vecInf(in.pos);
+        tmNorm *= normInf(in.tm);
+      }
+      cullS1 = std::max(cullS1, posAbs + 1.0);
+      cullS2 = std::max(cullS2, boxAbs + 1.0);
+      cullK3 = std::max(cullK3, 2e-5 * cond);
+      cullK4 = std::max(cullK4, 2.0 * tmNorm * (in.obj_type == QA_OBJ_MESH ? (double) r.nearPad : 0.0) + 1e-5 * (boxAbs + 1.0));
+      if (!std::isfinite(cond) || !std::isfinite(boxAbs) || !std::isfinite(posAbs) || !std::isfinite(tmNorm)) cullOk = false;
     }
+    c->csCullS1 = (float) cullS1; c->csCullS2 = (float) cullS2; c->csCullK3 = (float) cullK3; c->csCullK4 = (float) cullK4;
+    if (!std::isfinite(c->csCullS1) || !std::isfinite(c->csCullS2) || !std::isfinite(c->csCullK3) || !std::isfinite(c->csCullK4)) cullOk = false;
+    c->csCullOk = cullOk;
+    if ((rc = DeviceCopy(c, cull, &c->csCullDev)) != QA_OK) return rc;
     if ((rc = DeviceCopy(c, ci, &c->csInstDev)) != QA_OK) return rc;
   }
   if ((rc = DeviceCopy(c, dmeshes, &ds.mesh)) != QA_OK) return rc;
@@ -721,6 +757,8 @@ static int PrepareScene(qa_ctx *c)
   ds.csTris = c->csTrisDev;
   ds.csLeafBox = c->csLeafBoxDev;
   ds.csInst = c->csInstDev;
+  ds.csCull = c->csCullDev;
+  ds.csCullS1 = c->csCullS1; ds.csCullS2 = c->csCullS2; ds.csCullK3 = c->csCullK3; ds.csCullK4 = c->csCullK4;
   ds.csItems = DevEnv("QA_CS_ITEMS") ? (uint32_t) atoi(DevEnv("QA_CS_ITEMS")) : 896u;
   ds.csSlots = DevEnv("QA_CS_SLOTS") ? (uint32_t) atoi(DevEnv("QA_CS_SLOTS")) : 112u;
   if (ds.csSlots < 64u) ds.csSlots = 64u;     // an instance enters up to 64 rays at once
@@ -842,6 +880,8 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
+  ds.csCullOn = (c->optCsCull && c->csCullOk) ? 1u : 0u;
+  ds.csForceExact = c->optCsForceExact;
   ds.csPoolLimit = DevEnv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(DevEnv("QA_CS_POOL"))) : c->optCsPool;
   const size_t ldsBytes = pmOn ? c->ldsBytesPm : (cs ? c->ldsBytesCs : c->ldsBytes);
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
@@ -1239,7 +1279,9 @@ int qa_set_option(qa_ctx *c, const char *name, long long value)
   if (n == "coop") {
     c->optCoop = value != 0;
     if (c->haveScene) return SelectKernel(c);
-  } else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
+  } else if (n == "cs_cull") c->optCsCull = value != 0;
+  else if (n == "cs_force_exact") c->optCsForceExact = (uint32_t) (value & 3);
+  else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
   else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "tile_order") c->tileOrder = value != 0;
   else if (n == "staged_groups") {

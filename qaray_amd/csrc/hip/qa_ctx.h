@@ -123,6 +123,10 @@ struct qa_ctx {
   size_t ldsBytesCs = 0;
   const uint4 *csNodesDev = nullptr, *csTrisDev = nullptr, *csLeafBoxDev = nullptr;   // scene allocations (freed with the scene)
   const CsInst *csInstDev = nullptr;
+  const CsCull *csCullDev = nullptr;
+  float csCullS1 = 0, csCullS2 = 0, csCullK3 = 0, csCullK4 = 0;
+  bool csCullVariant = false;    // the cooperative kernel chosen tests the nodes' bounds first (SelectKernel)
+  bool csCullOk = false;         // the widening constants are finite (otherwise every instance is visited)
   int blocksPerCUCs = 2;
   int blocksPerCUPm = 2;
   uint32_t stackDepthPm = 0;   // LDS stack entries per lane when the kd-tree gather runs on it
@@ -138,6 +142,8 @@ struct qa_ctx {
   std::string launchedName;     // what the last qa_render_* call really launched (empty before the first)
   // qa_set_option
   bool optCoop = true;          // "coop": cooperative mesh walks (qa_kernel_cs.h) where the scene allows them
+  bool optCsCull = true;        // "cs_cull": instance culling in the cooperative kernel's sweeps (0: every instance is visited; A/B tests)
+  uint32_t optCsForceExact = 0; // "cs_force_exact": tests of the exact walks (bit 0 closest-hit, bit 1 shadow queries)
   uint32_t optCsPool = 0;       // "cs_pool_limit": upper bound for the walks' pool capacity (tests force the overflow path)
   bool optVerbose = false;      // "verbose": tree / launch-shape report on stderr at upload
 };

@@ -51,6 +51,11 @@ namespace qa {
 #endif
 #define QA_CS_RES_WORDS 256             /* per wave: 64 closest-hit keys (2 words each) or QA_CS_LIGHT_BATCH x 64 any-hit results */
 
+// lanes below this one that are set in m (v_mbcnt: two instructions)
+__device__ __forceinline__ uint32_t csLanePrefix(unsigned long long m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
 __device__ __forceinline__ void csWaveSync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -162,20 +167,22 @@ __device__ __forceinline__ void csRun(const DScene &sc, const CsLds &L, uint32_t
           }
         }
       }
-      // children the ray enters: inner ones onto the node stack, leaves onto the leaf stack (ballot + prefix, no atomics)
+      // children the ray enters: inner ones onto the node stack, leaves onto the leaf stack (ballot + lane prefix, no atomics).
+      // Whether the pool has room is decided for the whole wave: without room (rarely) none of this push's items is stored and
+      // their queries are repeated exactly.
 #define QA_CS_PUSH(K, W)                                                                                     \
       {                                                                                                      \
-        const bool p = K < INF, pl = p && (W & QA_BVH_LEAF_BIT), pn = p && !(W & QA_BVH_LEAF_BIT);          \
-        const unsigned long long mn = __ballot(pn), ml = __ballot(pl);                                       \
-        const uint32_t room = cap - nNode - nLeaf, cn = (uint32_t) __popcll(mn), cl = (uint32_t) __popcll(ml); \
-        if (p) {                                                                                             \
-          const uint32_t at = pn ? (uint32_t) __popcll(mn & ((1ull << lane) - 1ull)) : cn + (uint32_t) __popcll(ml & ((1ull << lane) - 1ull)); \
-          if (at < room) L.items[pn ? nNode + at : cap - nLeaf - 1u - (at - cn)] = W | (slot << QA_CS_SLOT_SHIFT); \
-          else atomicOr(&L.flags[owner], CLOSEST ? 1u : (1u << mx));   /* pool full: this query is repeated exactly */ \
+        const bool p = K < INF, lf = (W & QA_BVH_LEAF_BIT) != 0;                                             \
+        const unsigned long long mn = __ballot(p && !lf), ml = __ballot(p && lf);                            \
+        const uint32_t cn = (uint32_t) __popcll(mn), cl = (uint32_t) __popcll(ml);                           \
+        if (__builtin_expect(cn + cl > cap - nNode - nLeaf, 0)) {                                            \
+          if (p) atomicOr(&L.flags[owner], CLOSEST ? 1u : (1u << mx));                                       \
+        } else {                                                                                             \
+          const uint32_t at = lf ? (cap - nLeaf - 1u) - csLanePrefix(ml) : nNode + csLanePrefix(mn);         \
+          if (p) L.items[at] = W | (slot << QA_CS_SLOT_SHIFT);                                               \
+          nNode += cn;                                                                                       \
+          nLeaf += cl;                                                                                       \
         }                                                                                                    \
-        const uint32_t okn = cn < room ? cn : room, okl = (cn + cl <= room) ? cl : (room - okn);             \
-        nNode += okn;                                                                                        \
-        nLeaf += okl;                                                                                        \
       }
       QA_CS_PUSH(k3, w3)
       if (!quad) {
@@ -413,7 +420,7 @@ __device__ __forceinline__ void csEnter(const CsLds &L, unsigned long long mk, b
 {
   const unsigned lane = __lane_id();
   if (coop) {
-    const uint32_t at = (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
+    const uint32_t at = csLanePrefix(mk);
     const uint32_t slot = nSlots + at;
     L.rays[2 * slot] = make_uint4(__float_as_uint(r.p.x), __float_as_uint(r.p.y), __float_as_uint(r.p.z), __float_as_uint(limit));
     L.rays[2 * slot + 1] = make_uint4(__float_as_uint(r.d.x), __float_as_uint(r.d.y), __float_as_uint(r.d.z), csMeta(lane, x, pad));
@@ -425,6 +432,37 @@ __device__ __forceinline__ float csPad(const M &m, f3 o)
 {
   const float oMax = qmax(qmax(qabs(o.x), qabs(o.y)), qabs(o.z));
   return m.nearPad + (QA_SLACK_SCALE * 1e-6f) * (oMax + m.absMax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instance culling.  The reference visits every node for every ray (Scene::TraceNodeNormal / TraceNodeShadow,
+// src/scene/scene.cpp:35-74; it computes a child bounding box at src/parser/xmlload.cpp:105 and never uses it); nothing requires
+// reproducing that cost.  A node's object can only be hit inside its bounds, so a ray that misses the object's ROOT-space box
+// (DScene::csCull), or enters it beyond the distance held, skips the node: no record loads, no transform, no test - when the
+// whole wave skips it; a lane that misses while others do not sits the node out, which changes nothing either.
+// How much the box must be widened: an accepted hit is a point o_n + d_n * t of the NODE-space ray, which the fp32 transforms
+// (Node::ToNodeCoords: itm * (p - pos) and itm * ((p + d) - pos) - ...) have moved by up to ~4 eps |itm| (|o| + |pos|) in the
+// origin and ~8 eps |itm| (|o| + |d| + |pos|) in the direction - the latter times t, which is at most the distance to the far
+// side of the box.  Back in root space that is <= 14 eps cond(tm) (oMax + |pos| + 1) (oMax + |box|): csCullK3 holds 2e-5 cond(tm)
+// (20 x that), csCullK4 the meshes' own acceptance slack (DMesh::nearPad) and the rounding of this test's slab arithmetic
+// (approximate reciprocals: a few ulp).  NaNs (a zero direction component against a box face through the origin) never cull.
+// ---------------------------------------------------------------------------------------------
+struct CsCullRay { f3 rd; float pad; };   // (four values alive during a sweep; the origin is the ray's own)
+__device__ __forceinline__ CsCullRay csCullRay(const DScene &sc, const Ray &r0)
+{
+  const float oMax = qmax(qmax(qabs(r0.p.x), qabs(r0.p.y)), qabs(r0.p.z));
+  CsCullRay c;
+  c.pad = __builtin_fmaf((oMax + sc.csCullS1) * (oMax + sc.csCullS2), sc.csCullK3, sc.csCullK4);
+  c.rd = F3(__builtin_amdgcn_rcpf(r0.d.x), __builtin_amdgcn_rcpf(r0.d.y), __builtin_amdgcn_rcpf(r0.d.z));
+  return c;
+}
+__device__ __forceinline__ bool csCullPass(const CsCull &b, const CsCullRay &c, f3 o, float limit)
+{
+  const f3 pd = F3(c.pad, c.pad, c.pad);
+  const f3 p0 = ((ld3(b.lo) - pd) - o) * c.rd, p1 = ((ld3(b.hi) + pd) - o) * c.rd;   // (the box widened: scalar operands, the additions are scalar-vector)
+  const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(p0.x, p1.x), __builtin_fminf(p0.y, p1.y)), __builtin_fminf(p0.z, p1.z));
+  const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(p0.x, p1.x), __builtin_fmaxf(p0.y, p1.y)), __builtin_fmaxf(p0.z, p1.z));
+  return !(en > limit || en > ex || ex < 0.f);
 }
 
 // Scene::TraceNodeNormal (traceClosest of qa_kernel.h) for the lanes with `act`; every lane of the wave calls this.
@@ -450,7 +488,7 @@ __device__ __forceinline__ RayDiff csRayDiff(const DScene &sc, const Ray &world,
   return wd;
 }
 
-template <bool TEX>
+template <bool TEX, bool CULL>
 __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L, bool act, const Ray &world, bool primary, uint32_t pxy, int sidx, Hit &h, TexHit &th,
                                                DCounters &cnt)
 {
@@ -480,7 +518,13 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
     if ((uint32_t) (old >> 32) == __float_as_uint(bestZ) && old != mine) L.flags[lane] = 1; /* a triangle at exactly that distance: order decides */ \
     if (mine < old) *key = mine;                                                                                                \
   }
+  const CsCullRay cull = csCullRay(sc, r0);
   for (int k = 1; k < sc.num_inst; ++k) {
+    bool in = act;   // this lane's ray can meet node k's object
+    if (CULL && sc.csCullOn) {
+      in = act && csCullPass(ldTable(sc.csCull + k), cull, r0.p, bestZ);
+      if (!__any(in)) continue;
+    }
     const CsInst ci = ldTable(sc.csInst + k);
     const int type = ci.type;
     if (type == QA_OBJ_NONE) continue;
@@ -491,7 +535,7 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
       hh.node = -1;
       hh.p = hh.N = F3(0, 0, 0);
       hh.front = true;
-      const bool hit = act && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, !TEX) : hitPlane(r, hh, k, !TEX));
+      const bool hit = in && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, !TEX) : hitPlane(r, hh, k, !TEX));
       if (hit) {
         bestZ = hh.z;
         bestK = k;
@@ -505,7 +549,7 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
     }
     // (gate against the spheres and planes met so far: any limit not below the final answer is safe, and a triangle at
     // exactly the distance held raises the flag whatever the gate saw)
-    const bool go = act && csGate(ci, r, bestZ);
+    const bool go = in && csGate(ci, r, bestZ);
     const bool coop = go && ci.useWide && insideCancelReach(ci, r.p);
     exact = exact || (go && !coop);
     const unsigned long long mk = __ballot(coop);
@@ -533,7 +577,7 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
   float meshZ;
   {
     const unsigned long long key = csKeys(L)[lane];
-    exact = exact || L.flags[lane] != 0;
+    exact = exact || L.flags[lane] != 0 || (act && (sc.csForceExact & 1u));   // (option "cs_force_exact": tests of the exact walks)
     elem = (uint32_t) key;
     meshZ = __uint_as_float((uint32_t) (key >> 32));
     // a sphere or plane met after the last run of the pool
@@ -702,6 +746,7 @@ __device__ __forceinline__ void csShadowRay(const qa_light &l, f3 p, Ray &w, flo
 // onwards; on return li is where the following batch starts and nb the lights taken), for the lanes with `lit`: bit jj of the
 // result = light jj of the batch occluded.  The reference stops at the first node that occludes; which one does not matter.
 // The pool runs once, after the sweeps of all the batch's lights (and, rarely, in between when it cannot take an instance's rays).
+template <bool CULL>
 __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds &L, bool lit, f3 p, int &li, uint32_t &nb, DCounters &cnt)
 {
   const unsigned lane = __lane_id();
@@ -723,9 +768,14 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
     GroupRay grp;
     grp.node = -1;
     grp.ray = r0;
+    const CsCullRay cull = csCullRay(sc, r0);
     for (int k = 1; k < sc.num_inst; ++k) {
-      const bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
-      if (!__any(open)) break;                                   // settled for the whole wave: next light
+      bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
+      if (!__any(open)) break;                             // settled for the whole wave: next light
+      if (CULL && sc.csCullOn) {
+        open = open && csCullPass(ldTable(sc.csCull + k), cull, r0.p, tmax);   // ... and its ray can meet node k's object
+        if (!__any(open)) continue;
+      }
       const CsInst ci = ldTable(sc.csInst + k);
       const int type = ci.type;
       if (type == QA_OBJ_NONE) continue;
@@ -765,6 +815,7 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
   }
   QA_TACC(cnt.sl[17], tSweep)
   // ---- the exact repeats
+  if (sc.csForceExact & 2u) { occl = 0; redo = lit ? (1u << nb) - 1u : 0u; }   // (option "cs_force_exact": tests of the exact walks)
   redo &= ~occl;
 #ifdef QA_STAMPS
   if (lane == 0) cnt.sl[16] += (unsigned long long) __popcll(__ballot(lit && redo != 0));
@@ -866,7 +917,10 @@ __host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) {
 #define QA_PST_PRIMARY 0x200u
 #define QA_PST_ABSORB(s) ((int) ((s) >> 16) - 1)
 
-template <bool LIGHTS, bool TEX>
+// CULL: the sweeps test every node's root-space bounds first (instance culling).  A variant of its own because the four values
+// the test keeps alive during a sweep cost the untextured kernel more in spills than culling returns on scenes of a few nodes
+// (C4, 10 nodes: 4 530 without the code, 4 010 with it; a field of 38 nodes: 1 470 -> 2 100 Msamples/s): qa_capi.hip SelectKernel.
+template <bool LIGHTS, bool TEX, bool CULL>
 __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -979,7 +1033,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     Hit h;
     TexHit th;
     QA_T(tC)
-    const bool found = csTraceClosest<TEX>(sc, L, act, ray, (pst & QA_PST_PRIMARY) != 0, pxy, sidx, h, th, cnt);
+    const bool found = csTraceClosest<TEX, CULL>(sc, L, act, ray, (pst & QA_PST_PRIMARY) != 0, pxy, sidx, h, th, cnt);
     QA_TACC(cnt.sl[2], tC)
     QA_T(tD)
 
@@ -1069,7 +1123,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         QA_T(tL)
         int li = 0;
         uint32_t nb = 0;
-        const uint32_t occl = csShadowBatch(sc, L, lit, ray.p, li, nb, cnt);
+        const uint32_t occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
         if (lit) pL = pL + litT * csLightSum(terms, nb, occl);
         QA_TACC(cnt.sl[5], tL)
       }

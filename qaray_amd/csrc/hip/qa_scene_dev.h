@@ -143,6 +143,15 @@ struct alignas(64) CsInst {
 };
 static_assert(sizeof(CsInst) == 256, "CsInst must be 64 dwords");
 
+// Instance culling (qa_integrate_cs's sweeps): bounds of a scene-graph node's object in ROOT space (the eight corners of
+// its node-space box through tm * p + pos of every level, evaluated in double on the host), one scalar load of 8 dwords.
+// A node without an object carries an empty box (lo > hi: never entered).
+struct alignas(32) CsCull {
+  float lo[3], pad0;
+  float hi[3], pad1;
+};
+static_assert(sizeof(CsCull) == 32, "CsCull must be 8 dwords");
+
 #define QA_LANE_SLOTS 6   /* per-lane LDS floats behind the traversal stack: running mean and variance of the pixel */
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
 #define QA_KARG_MESH 4
@@ -184,6 +193,13 @@ struct DScene {
   const uint4 *csTris;
   const uint4 *csLeafBox;
   const CsInst *csInst;        // [num_inst]
+  // Instance culling: csCull[k] = root-space bounds of node k's object; a ray whose origin has the largest coordinate oMax
+  // tests them widened by (oMax + csCullS1) * (oMax + csCullS2) * csCullK3 + csCullK4 (qa_kernel_cs.h csCullPad: what the
+  // fp32 node transforms can move a hit point by, with margin).  csCullOn = 0: every instance is visited (option "cs_cull").
+  const CsCull *csCull;        // [num_inst]
+  float csCullS1, csCullS2, csCullK3, csCullK4;
+  uint32_t csCullOn;
+  uint32_t csForceExact;       // tests (option "cs_force_exact"): bit 0 = every closest-hit query, bit 1 = every shadow query goes to the exact walks
   uint32_t csItems, csSlots;   // per-wave pool capacity (items) and ray slots of the LDS layout
   // resident scenes only: the tables themselves, in the kernel-argument segment
   qa_instance instv[QA_KARG_INST];

@@ -245,6 +245,94 @@ def test_cooperative_walks_equal_the_sequential_megakernel(tmp_path, case):
         assert all(cnts[mode][k] == cnts["stats"][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), mode
 
 
+def _write_many_nodes_scene(path, n_side=6, spot=False):
+    """A field of n_side^2 objects (spheres, every fifth a rotated teapot instance) on a floor under two lights: 38 nodes."""
+    objs = ['<object type="plane" name="floor" material="floor"><scale value="60"/></object>']
+    for i in range(n_side):
+        for j in range(n_side):
+            x, y = (i - (n_side - 1) / 2) * 7.0, (j - (n_side - 1) / 2) * 7.0
+            if (i + j) % 5 == 0:
+                objs.append('<object type="obj" name="teapot-low.obj" material="m%d"><scale value="0.25"/><rotate angle="%d" z="1"/>'
+                            '<translate x="%g" y="%g" z="0"/></object>' % ((i * 7 + j) % 3, (i * 37 + j * 11) % 360, x, y))
+            else:
+                objs.append('<object type="sphere" name="s%d_%d" material="m%d"><scale value="%g"/><translate x="%g" y="%g" z="2.2"/></object>'
+                            % (i, j, (i * 7 + j) % 3, 1.5 + ((i * 3 + j) % 4) * 0.4, x, y))
+    mats = ('<material type="blinn" name="floor"><diffuse r="0.8" g="0.8" b="0.8"/><specular value="0"/></material>'
+            '<material type="blinn" name="m0"><diffuse r="0.8" g="0.2" b="0.2"/><specular value="0.6"/><glossiness value="30"/></material>'
+            '<material type="blinn" name="m1"><diffuse r="0.2" g="0.7" b="0.3"/><specular value="0.5"/><glossiness value="20"/><reflection value="0.4"/></material>'
+            '<material type="blinn" name="m2"><diffuse r="0.1" g="0.1" b="0.1"/><specular value="0.8"/><glossiness value="50"/><refraction value="0.9" index="1.5"/></material>')
+    lights = ('<light type="ambient" name="amb"><intensity value="0.1"/></light>'
+              '<light type="point" name="p1"><intensity value="0.7"/><position x="20" y="-30" z="40"/></light>'
+              '<light type="direct" name="d1"><intensity value="0.4"/><direction x="0.3" y="0.2" z="-1"/></light>')
+    cam = '<camera><position x="0" y="-70" z="35"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="35"/><width value="800"/><height value="600"/></camera>'
+    open(path, "w").write("<xml><scene>" + "".join(objs) + mats + lights + "</scene>" + cam + "</xml>")
+
+
+@pytest.mark.parametrize("case", ["many_nodes", "object", "tower", "caustics"])
+def test_instance_culling_changes_no_bit(tmp_path, case):
+    """The cooperative kernel's sweeps skip a scene-graph node when the rays of a wave all miss its root-space bounds (the
+    reference visits every node, src/scene/scene.cpp:35-74).  Same bits and cast counts with the test switched off (option
+    "cs_cull" = 0) and as the per-lane kernel; the many-nodes scene (38 nodes: spheres, rotated mesh instances, a point and a
+    direct light) also against the oracle."""
+    from oracle import binding as oracle
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    if case == "many_nodes":
+        xml = str(tmp_path / "many_nodes.xml")
+        _write_many_nodes_scene(xml)
+        size, spp = (160, 120), 2
+        blob = load_scene_blob(xml, size=size, asset_root=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes"))
+    else:
+        size, spp = (480, 270), 4
+        blob = load_scene_blob({"object": "example_project7_object.xml", "tower": "trc_scene_tower.xml", "caustics": "example_project12_caustics_glossy.xml"}[case], size=size)
+    w, h = size
+    outs, cnts = {}, {}
+    for mode in ("cull", "nocull", "own"):
+        c = hip.Context(0)
+        c.set_option("coop", 0 if mode == "own" else 1)
+        c.set_option("cs_cull", 1 if mode == "cull" else 0)
+        c.upload_scene(blob)
+        if mode != "own":
+            assert "qa_integrate_cs" in c.kernel_name(), c.kernel_name()
+            if case in ("many_nodes", "object"):
+                assert "CULL=1" in c.kernel_name(), c.kernel_name()   # (the variant that holds the test; "nocull" switches it off at run time)
+        c.reset_counters()
+        outs[mode] = c.render_region((0, 0, w, h), spp)
+        cnts[mode] = c.counters()
+        c.close()
+    for mode in ("nocull", "own"):
+        for a, b in zip(outs["cull"], outs[mode]):
+            assert np.array_equal(bits(a), bits(b)), mode
+        assert cnts["cull"] == cnts[mode], mode
+    if case == "many_nodes":
+        o = oracle.render(blob, (0, 0, w, h), spp)
+        assert np.array_equal(bits(outs["cull"][1]), bits(o[1])) and np.array_equal(outs["cull"][2], o[2])
+        assert (cnts["cull"]["casts_normal"], cnts["cull"]["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
+        assert rmse(np.nan_to_num(outs["cull"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
+
+
+@pytest.mark.parametrize("scene", ["trc_scene_tower.xml", "example_project7_object.xml"])
+def test_exact_walks_alone_return_the_frame(scene):
+    """Option "cs_force_exact": every closest-hit (bit 0) / shadow (bit 1) query of the cooperative kernel takes the path that
+    ties, failed order checks and a full pool take - the exact sequential walks on the reference's trees.  Same bits as the
+    normal frame and as the counting kernel (the reference's walk)."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 240, 136, 2
+    c = hip.Context(0)
+    c.upload_scene(load_scene_blob(scene, size=(w, h)))
+    ref = c.render_region((0, 0, w, h), spp, stats=True)
+    for force in (0, 1, 2, 3):
+        c.set_option("cs_force_exact", force)
+        out = c.render_region((0, 0, w, h), spp)
+        assert "qa_integrate_cs" in c.kernel_name(), c.kernel_name()
+        for a, b in zip(out, ref):
+            assert np.array_equal(bits(a), bits(b)), force
+    c.close()
+
+
 def test_exact_repeat_is_exercised_and_invisible(ctx, tmp_path):
     """Coincident sheets: the staged integrator must send rays to wf_redo (ties / failed order checks) - and the frame
     must not show it."""
