@@ -94,8 +94,8 @@ static int SelectKernel(qa_ctx *c)
     resident = 2;
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
   // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
-  // (at most QA_CS_LIGHT_BATCH = 4 non-ambient lights: their unshadowed terms are kept in registers while the wave sweeps the
-  // scene for the shadow rays, qa_kernel_cs.h csLightTerms; scenes with more lights keep qa_integrate)
+  // (any number of lights: their shadow queries are pooled QA_CS_LIGHT_BATCH = 4 lights at a time; with more than one batch the
+  // surface waits in the slab DScene::csSurf between batches, qa_kernel_cs.h)
   c->kernelCs = nullptr;
   {
     const char *e = DevEnv("QA_COOP");
@@ -105,16 +105,20 @@ static int SelectKernel(qa_ctx *c)
       const qa_light *hl = QA_BLOB_PTR(qa_light, c->hostBlob.data(), fh->off_lights);
       for (uint32_t i = 0; i < fh->num_lights; ++i) shadowLights += hl[i].type != QA_LIGHT_AMBIENT;
     }
-    if (!c->resident && !c->area && c->csFits && shadowLights <= QA_CS_LIGHT_BATCH && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
+    if (!c->resident && !c->area && c->csFits && (shadowLights <= QA_CS_LIGHT_BATCH || c->ds.csSurf) && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
       // instance culling (qa_kernel_cs.h): the textured variants always (it pays from a handful of nodes on: C3, 9 nodes, + 4 %), the
       // untextured ones on scenes of more than 12 nodes (their register budget: see the kernel's comment)
       c->csCullVariant = c->csCullOk && (c->textured || c->ds.num_inst > 12);
-      if (c->csCullVariant)
-        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, true> : (KernelFn) qa_integrate_cs<true, false, true>)
-                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, true> : (KernelFn) qa_integrate_cs<false, false, true>);
+      const bool many = shadowLights > QA_CS_LIGHT_BATCH;   // (those variants always test the nodes' bounds)
+      if (many) c->csCullVariant = c->csCullOk;
+      if (many)
+        c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true, true, true, true> : (KernelFn) qa_integrate_cs<true, false, true, true>;
+      else if (c->csCullVariant)
+        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, true, false> : (KernelFn) qa_integrate_cs<true, false, true, false>)
+                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, true, false> : (KernelFn) qa_integrate_cs<false, false, true, false>);
       else
-        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, false> : (KernelFn) qa_integrate_cs<true, false, false>)
-                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, false> : (KernelFn) qa_integrate_cs<false, false, false>);
+        c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, false, false> : (KernelFn) qa_integrate_cs<true, false, false, false>)
+                             : (c->textured ? (KernelFn) qa_integrate_cs<false, true, false, false> : (KernelFn) qa_integrate_cs<false, false, false, false>);
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) c->kernelCs, QA_BLOCK, c->ldsBytesCs) != hipSuccess || n < 1) n = 2;
       c->blocksPerCUCs = n > 8 ? 8 : n;
@@ -708,6 +712,18 @@ static int PrepareScene(qa_ctx *c)
     HIP_TRY(hipMalloc(&p, threads * QA_MAX_PATH * QA_REC_FLOATS * sizeof(float)));
     c->sceneAllocs.push_back(p);
     ds.areaScratch = static_cast<float *>(p);
+  }
+  {
+    // more shadow-casting lights than qa_integrate_cs takes in one batch: the slab its surface waits in between batches
+    int shadowLights = 0;
+    for (uint32_t i = 0; i < h->num_lights; ++i) shadowLights += light[i].type != QA_LIGHT_AMBIENT;
+    if (shadowLights > QA_CS_LIGHT_BATCH && !area) {
+      const size_t threads = (size_t) c->numCUs * 8 * QA_BLOCK;
+      void *p = nullptr;
+      HIP_TRY(hipMalloc(&p, threads * 13 * sizeof(float)));
+      c->sceneAllocs.push_back(p);
+      ds.csSurf = static_cast<float *>(p);
+    }
   }
   if (textured) {
     std::vector<int32_t> mtex(8 * (size_t) h->num_materials, -1);

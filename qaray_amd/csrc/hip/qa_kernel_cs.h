@@ -862,16 +862,19 @@ __device__ __forceinline__ f3 csLightTerm(const qa_light &l, float normCoefDI, f
 // them in table order afterwards, an occluded light's term times 0.0f (the reference's term with the factor 0.0f is a zero of
 // some sign - or a NaN exactly when the unshadowed term is not finite - and so is this product; a sum that started from +0
 // does not see the sign of a zero).  That way the surface (normal, view direction, the sampled colours, the glossiness: 13
-// values) is dead while the wave sweeps the scene for its shadow rays, and only three values per light are kept.  At most
-// QA_CS_LIGHT_BATCH non-ambient lights (SelectKernel, qa_capi.hip: scenes with more keep qa_integrate).
+// values) is dead while the wave sweeps the scene for its shadow rays, and only three values per light are kept.  Lights are
+// taken QA_CS_LIGHT_BATCH at a time (csLightTerms from table index li0 on, then csShadowBatch, then csLightSum continuing the
+// running sum); scenes with more shadow-casting lights than one batch park the surface in a global slab (DScene::csSurf, one
+// coalesced column per value) and read it back before each further batch - explicitly, and only there, instead of leaving 13
+// values to the register allocator in every scene.
 struct CsTerms { f3 c0, c1, c2, c3; };
-__device__ __forceinline__ CsTerms csLightTerms(const DScene &sc, bool lit, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss)
+__device__ __forceinline__ CsTerms csLightTerms(const DScene &sc, bool lit, int li0, f3 p, f3 N, f3 V, f3 kd, f3 ks, float gloss)
 {
   CsTerms t;
   t.c0 = t.c1 = t.c2 = t.c3 = F3(0, 0, 0);
   const float normCoefDI = 1.f / (float) sc.num_lights;
   uint32_t j = 0;
-  for (int li = 0; li < sc.num_lights && j < QA_CS_LIGHT_BATCH; ++li) {
+  for (int li = li0; li < sc.num_lights && j < QA_CS_LIGHT_BATCH; ++li) {
     const qa_light l = ldTable(sc.light + li);
     if (l.type == QA_LIGHT_AMBIENT) continue;
     f3 c = F3(0, 0, 0);
@@ -884,9 +887,8 @@ __device__ __forceinline__ CsTerms csLightTerms(const DScene &sc, bool lit, f3 p
   }
   return t;
 }
-__device__ __forceinline__ f3 csLightSum(const CsTerms &t, uint32_t nb, uint32_t occl)
+__device__ __forceinline__ f3 csLightSum(f3 sum, const CsTerms &t, uint32_t nb, uint32_t occl)
 {
-  f3 sum = F3(0, 0, 0);
   if (nb > 0) sum = sum + ((occl & 1u) ? t.c0 * 0.0f : t.c0);
   if (nb > 1) sum = sum + ((occl & 2u) ? t.c1 * 0.0f : t.c1);
   if (nb > 2) sum = sum + ((occl & 4u) ? t.c2 * 0.0f : t.c2);
@@ -920,7 +922,9 @@ __host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) {
 // CULL: the sweeps test every node's root-space bounds first (instance culling).  A variant of its own because the four values
 // the test keeps alive during a sweep cost the untextured kernel more in spills than culling returns on scenes of a few nodes
 // (C4, 10 nodes: 4 530 without the code, 4 010 with it; a field of 38 nodes: 1 470 -> 2 100 Msamples/s): qa_capi.hip SelectKernel.
-template <bool LIGHTS, bool TEX, bool CULL>
+// MANY: more shadow-casting lights than one batch (QA_CS_LIGHT_BATCH): the surface is parked in DScene::csSurf and the further
+// batches follow.  A variant of its own for the same reason: with that loop compiled in, scenes of one batch lose 6 - 11 %.
+template <bool LIGHTS, bool TEX, bool CULL, bool MANY>
 __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -1101,7 +1105,15 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     if (LIGHTS) {
       if (__any(lit)) {
         QA_T(tLt)
-        terms = csLightTerms(sc, lit, p, N, V, sf.kd, sf.ks, sf.gloss);
+        terms = csLightTerms(sc, lit, 0, p, N, V, sf.kd, sf.ks, sf.gloss);
+        if (MANY && lit) {
+          // more lights than one batch: the surface waits in the slab (column f of this lane: csSurf[f * lanes + lane id])
+          const size_t stride = (size_t) gridDim.x * QA_BLOCK;
+          float *sv = sc.csSurf + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+          const float v[13] = {N.x, N.y, N.z, V.x, V.y, V.z, sf.kd.x, sf.kd.y, sf.kd.z, sf.ks.x, sf.ks.y, sf.ks.z, sf.gloss};
+#pragma unroll
+          for (int f = 0; f < 13; ++f) sv[f * stride] = v[f];
+        }
         QA_TACC(cnt.sl[18], tLt)
       }
     }
@@ -1123,8 +1135,24 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         QA_T(tL)
         int li = 0;
         uint32_t nb = 0;
-        const uint32_t occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
-        if (lit) pL = pL + litT * csLightSum(terms, nb, occl);
+        uint32_t occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
+        f3 dl = csLightSum(F3(0, 0, 0), terms, nb, occl);
+        if (MANY) {
+          // the further batches of a scene with many lights: surface back from the slab, terms, shadow queries, sum - in table order
+          while (li < sc.num_lights) {
+            const int li0 = li;
+            const size_t stride = (size_t) gridDim.x * QA_BLOCK;
+            const float *sv = sc.csSurf + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+            float v[13];
+#pragma unroll
+            for (int f = 0; f < 13; ++f) v[f] = lit ? sv[f * stride] : 0.f;
+            terms = csLightTerms(sc, lit, li0, ray.p, F3(v[0], v[1], v[2]), F3(v[3], v[4], v[5]), F3(v[6], v[7], v[8]), F3(v[9], v[10], v[11]), v[12]);
+            occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
+            if (!nb) break;   // (only ambient lights were left)
+            dl = csLightSum(dl, terms, nb, occl);
+          }
+        }
+        if (lit) pL = pL + litT * dl;
         QA_TACC(cnt.sl[5], tL)
       }
     }

@@ -199,6 +199,7 @@ struct DScene {
   const CsCull *csCull;        // [num_inst]
   float csCullS1, csCullS2, csCullK3, csCullK4;
   uint32_t csCullOn;
+  float *csSurf;               // scenes with more than QA_CS_LIGHT_BATCH shadow-casting lights: [13][grid lanes] surface columns (qa_kernel_cs.h), else nullptr
   uint32_t csForceExact;       // tests (option "cs_force_exact"): bit 0 = every closest-hit query, bit 1 = every shadow query goes to the exact walks
   uint32_t csItems, csSlots;   // per-wave pool capacity (items) and ray slots of the LDS layout
   // resident scenes only: the tables themselves, in the kernel-argument segment

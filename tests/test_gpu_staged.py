@@ -437,11 +437,10 @@ def test_auto_is_the_megakernel_and_staged_runs_on_request_only():
         assert np.array_equal(bits(x), bits(y)) and np.array_equal(bits(x), bits(z))
 
 
-def test_many_lights_keep_the_per_lane_kernel(tmp_path):
-    """33 non-ambient lights over a global-memory mesh: the cooperative kernel keeps the unshadowed terms of at most four
-    lights in registers while it sweeps the scene for their shadow rays, so such a scene is rendered by qa_integrate whatever
-    the "coop" option says (round 2's cooperative kernel kept one occlusion bit per light in a 32-bit mask: lights 32.. aliased).
-    Depth / cast counts as the oracle."""
+def test_many_lights_are_pooled_in_batches(tmp_path):
+    """33 non-ambient lights over a global-memory mesh: the cooperative kernel pools their shadow queries four lights at a
+    time, the surface waiting in a global slab between batches (round 2's kernel kept one occlusion bit per light in a 32-bit
+    mask: lights 32.. aliased).  Same bits as the per-lane kernel, depth / cast counts as the oracle."""
     from oracle import binding as oracle
     from qaray_amd import hip
     from qaray_amd.host import load_scene_blob
@@ -458,7 +457,7 @@ def test_many_lights_keep_the_per_lane_kernel(tmp_path):
         c = hip.Context(0)
         c.set_option("coop", 1 if mode == "coop" else 0)
         c.upload_scene(blob)
-        assert "qa_integrate_cs" not in c.kernel_name(), c.kernel_name()
+        assert ("qa_integrate_cs" in c.kernel_name()) == (mode == "coop"), c.kernel_name()
         c.reset_counters()
         outs[mode] = c.render_region((0, 0, w, h), spp)
         cnts[mode] = c.counters()
