@@ -1,0 +1,33 @@
+"""The compiler hazard behind the photon-walk nondeterminism of rounds 1 / 2 (profiles/round03/photon_walk_root_cause.txt):
+hipcc placed a register-allocator spill STORE at the head of a control-flow join block, ahead of the `s_or_b64 exec, exec, ...` that
+re-enables the lanes which skipped the preceding divergent region; those lanes never stored, and the matching reload replaced their good
+register contents by whatever the scratch slot held.  The build keeps the gfx950 assembly of every translation unit (-save-temps=obj);
+no shipped kernel may contain that pattern, and the checker must find it in the excerpt of the kernel that did."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "tools", "isa_exec_spill_check.py")
+
+
+def _run(path):
+    return subprocess.run([sys.executable, CHECK, path], stdout=subprocess.PIPE, text=True).stdout
+
+
+def test_checker_finds_the_hazard_in_the_kernel_that_had_it():
+    out = _run(os.path.join(ROOT, "tests", "golden", "isa", "photon_inline_128vgpr_excerpt.s"))
+    assert "total hazardous spill stores: 2" in out, out
+    assert ".LBB8_459" in out and "offset:320" in out
+
+
+def test_shipped_kernels_are_free_of_it():
+    files = sorted(glob.glob(os.path.join(ROOT, "qaray_amd", "lib", "obj", "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if len(files) < 3:
+        pytest.skip("no assembly next to the objects (run __graft_entry__.build())")
+    for f in files:
+        out = _run(f)
+        assert "total hazardous spill stores: 0" in out, f + "\n" + out[-3000:]
