@@ -165,6 +165,11 @@ int qa_set_pipeline(qa_ctx *ctx, int mode);
  * Unknown names return QA_EINVAL. */
 int qa_set_option(qa_ctx *ctx, const char *name, long long value);
 
+/* Test support: fills the private (scratch) segment of every wave slot of the device with `pattern`, on every stream this context
+ * launches on, and waits.  A frame rendered afterwards must not depend on the pattern: one that does reads scratch memory it never
+ * wrote (the compiler hazard of DESIGN.md 5b; tests/test_gpu_parity.py renders with several patterns).  No reference counterpart. */
+int qa_debug_scrub_scratch(qa_ctx *ctx, uint32_t pattern);
+
 /* Launch geometry (0 = library default). blocks_per_cu * CUs persistent workgroups of `threads`. */
 int qa_set_launch_config(qa_ctx *ctx, int blocks_per_cu, int threads_per_block);
 

@@ -61,6 +61,19 @@ static KernelFn PickKernel(bool resident, bool lights, bool tex, bool area, bool
   return stats ? PickShading<false, true>(lights, tex, area) : PickShading<false, false>(lights, tex, area);
 }
 
+namespace qa {
+// qa_debug_scrub_scratch: every lane fills its private segment (2 KB here, more than any kernel of this library uses) with one
+// pattern and lingers, so that all wave slots of the chip are taken at once.  A frame that depends on the pattern reads scratch it
+// never wrote (the compiler's spill-before-mask-restore hazard).
+__global__ __launch_bounds__(256, 8) void qa_scrub_scratch(uint32_t pattern, uint32_t *never)
+{
+  volatile uint32_t a[512];
+  for (int i = 0; i < 512; ++i) a[i] = pattern;
+  for (int i = 0; i < 300; ++i) __builtin_amdgcn_s_sleep(127);
+  if (a[threadIdx.x] == 0x12345u && pattern != 0x12345u) never[0] = 1;
+}
+}  // namespace qa
+
 static const char *kStagedName = "staged: wf_logic + wf_cull + wf_trace + wf_redo";
 static std::string MegaName(const qa_ctx *c, bool cs)
 {
@@ -1305,6 +1318,27 @@ int qa_set_option(qa_ctx *c, const char *name, long long value)
     if (c->haveScene) SetKernelName(c);
   } else if (n == "verbose") c->optVerbose = value != 0;
   else return Fail(QA_EINVAL, "unknown option '" + n + "'");
+  return QA_OK;
+}
+
+int qa_debug_scrub_scratch(qa_ctx *c, uint32_t pattern)
+{
+  if (!c) return Fail(QA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  // eight waves per SIMD on every CU: every wave slot of the chip - and with it every private segment the next launch can get -
+  // holds a wave of this kernel at the same time (each lingers until the grid has been placed)
+  hipLaunchKernelGGL(qa::qa_scrub_scratch, dim3((unsigned) c->numCUs * 8), dim3(256), 0, c->stream, pattern, reinterpret_cast<uint32_t *>(c->dCounters));
+  HIP_TRY(hipGetLastError());
+  for (int g = 0; g < c->wf.numGroups; ++g)
+    if (c->wf.groups[g].stream) {
+      hipLaunchKernelGGL(qa::qa_scrub_scratch, dim3((unsigned) c->numCUs * 8), dim3(256), 0, c->wf.groups[g].stream, pattern, reinterpret_cast<uint32_t *>(c->dCounters));
+      HIP_TRY(hipGetLastError());
+    }
+  if (c->wf.redoStream) {
+    hipLaunchKernelGGL(qa::qa_scrub_scratch, dim3((unsigned) c->numCUs * 8), dim3(256), 0, c->wf.redoStream, pattern, reinterpret_cast<uint32_t *>(c->dCounters));
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
   return QA_OK;
 }
 

@@ -81,6 +81,7 @@ def lib():
         L.qa_get_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.qa_reset_kernel_time.argtypes = [C.c_void_p]
         L.qa_set_launch_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.qa_debug_scrub_scratch.argtypes = [C.c_void_p, C.c_uint32]
         L.qa_set_pipeline.argtypes = [C.c_void_p, C.c_int]
         L.qa_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
         L.qa_get_kernel_name.argtypes = [C.c_void_p]
@@ -268,6 +269,10 @@ class Context:
 
     def reset_kernel_time(self):
         _check(lib().qa_reset_kernel_time(self._h))
+
+    def scrub_scratch(self, pattern):
+        """qa_debug_scrub_scratch: every wave slot's private segment filled with `pattern` (tests: frames must not depend on it)."""
+        _check(lib().qa_debug_scrub_scratch(self._h, pattern & 0xFFFFFFFF))
 
     def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
         _check(lib().qa_set_launch_config(self._h, blocks_per_cu, threads_per_block))
