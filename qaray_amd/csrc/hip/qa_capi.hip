@@ -749,6 +749,36 @@ static int PrepareScene(qa_ctx *c)
       for (int k = 0; k < 5; ++k) if (mtex[8 * i + k] >= (int) h->num_texmaps) return Fail(QA_EINVAL, "bad texmap index");
     }
     if ((rc = DeviceCopy(c, mtex, &ds.mtlTex)) != QA_OK) return rc;
+    // file textures as float RGB: TextureFile::Sample divides every byte it reads by 255.0f (src/textures/texture.cpp:120-131) - 12
+    // divisions per bilinear tap, 384 per filtered lookup; the same IEEE division once per texel here gives the same bits
+    {
+      std::vector<uint32_t> toff(std::max<uint32_t>(h->num_textures, 1u), 0u);
+      std::vector<float> tex4;
+      try {
+        for (uint32_t i = 0; i < h->num_textures; ++i) {
+          const qa_texture &tx = textures[i];
+          toff[i] = (uint32_t) (tex4.size() / 4);
+          if (tx.type == QA_TEX_CHECKER || tx.width <= 0 || tx.height <= 0) continue;
+          const size_t n = (size_t) tx.width * (size_t) tx.height;
+          if (!inside(tx.off_texels, 3 * n)) return Fail(QA_EINVAL, "texture texels outside the blob");
+          const unsigned char *px = blob + tx.off_texels;
+          const size_t at = tex4.size();
+          tex4.resize(at + 4 * n);
+          for (size_t t = 0; t < n; ++t) {
+            tex4[at + 4 * t + 0] = px[3 * t + 0] / 255.0f;
+            tex4[at + 4 * t + 1] = px[3 * t + 1] / 255.0f;
+            tex4[at + 4 * t + 2] = px[3 * t + 2] / 255.0f;
+            tex4[at + 4 * t + 3] = 0.f;
+          }
+        }
+      } catch (const std::bad_alloc &) { return Fail(QA_ENOMEM, "out of memory"); }
+      if (tex4.size() / 4 > 0xFFFFFFFFull) return Fail(QA_EUNSUPPORTED, "more than 2^32 texels");
+      if (tex4.empty()) tex4.assign(4, 0.f);
+      const float *dt = nullptr;
+      if ((rc = DeviceCopy(c, tex4, &dt)) != QA_OK) return rc;
+      ds.texels = reinterpret_cast<const float4 *>(dt);
+      if ((rc = DeviceCopy(c, toff, &ds.texOff)) != QA_OK) return rc;
+    }
     // Texture::Sample's elliptical taps (src/core/texture.cpp:39-46), i = 1..31, host libm
     std::vector<float> taps(62);
     for (int i = 1; i < 32; ++i) {

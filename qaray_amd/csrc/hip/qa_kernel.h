@@ -1245,6 +1245,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   QA_T(tKernel)
   TexTables tt;
   tt.blob = sc.blob;
+  tt.texels = sc.texels;
+  tt.texOff = sc.texOff;
   tt.texmap = sc.texmap;
   tt.tex = sc.tex;
   tt.filter = sc.texFilter;

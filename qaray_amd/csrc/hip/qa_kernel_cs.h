@@ -957,6 +957,8 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   QA_T(tKernel)
   TexTables tt;
   tt.blob = sc.blob;
+  tt.texels = sc.texels;
+  tt.texOff = sc.texOff;
   tt.texmap = sc.texmap;
   tt.tex = sc.tex;
   tt.filter = sc.texFilter;

@@ -164,6 +164,8 @@ __global__ __launch_bounds__(QA_BLOCK) void qa_photon_emit(const DScene sc, cons
   if (t >= ep.count) return;
   TexTables tt;
   tt.blob = sc.blob;
+  tt.texels = sc.texels;
+  tt.texOff = sc.texOff;
   tt.texmap = sc.texmap;
   tt.tex = sc.tex;
   tt.filter = sc.texFilter;

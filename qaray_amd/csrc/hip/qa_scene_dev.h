@@ -173,6 +173,8 @@ struct DScene {
   const uint4 *resident;       // resident image (nodes | tris | shade | materials), or nullptr
   const qa_texmap *texmap;     // TEX variants: tables inside the blob
   const qa_texture *tex;
+  const float4 *texels;        // file textures as float RGB, 16 bytes per texel (qa_texture_dev.h), texture i from texOff[i]
+  const uint32_t *texOff;
   const float *texFilter;      // 31 x (x, y) elliptical filter taps (src/core/texture.cpp:39-46)
   float *areaScratch;          // AREA variants: [QA_MAX_PATH * 19][grid threads] hit log
   const int32_t *mtlTex;       // 8 ints per material: texmap of diffuse, specular, emission, reflection, refraction

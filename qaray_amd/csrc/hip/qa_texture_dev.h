@@ -25,6 +25,8 @@ struct TexHit {     // HitInfo::uvw, duvw[2], hasTexture (src/core/hitinfo.h:36-
 };
 
 struct TexTables {
+  const float4 *texels;   // every file texture as float RGB (x / 255.0f evaluated once per texel at upload: the same IEEE division, the
+  const uint32_t *texOff; // same bits), 16 bytes per texel: texture i starts at texels[texOff[i]]
   const unsigned char *blob;
   const qa_texmap *texmap;
   const qa_texture *tex;
@@ -115,11 +117,14 @@ __device__ __forceinline__ f3 tileClamp(f3 uvw)
   if (u.z < 0) u.z += 1;
   return u;
 }
-__device__ __forceinline__ f3 texel(const unsigned char *px) { return F3(px[0] / 255.0f, px[1] / 255.0f, px[2] / 255.0f); }
+// (the reference converts a texel with three divisions per bilinear corner, 12 per tap and 384 per filtered lookup,
+// src/textures/texture.cpp:120-131; here the quotients are tabulated per texel at upload and a corner is one 16-byte load)
+__device__ __forceinline__ f3 texel(const float4 *px) { const float4 t = *px; return F3(t.x, t.y, t.z); }
 
 // TextureChecker::Sample / TextureFile::Sample (src/textures/texture.cpp:97-137)
-__device__ __forceinline__ f3 textureSample(const TexTables &tt, const qa_texture &tx, f3 uvw)
+__device__ __forceinline__ f3 textureSample(const TexTables &tt, int ti, f3 uvw)
 {
+  const qa_texture &tx = tt.tex[ti];
   if (tx.type == QA_TEX_CHECKER) {
     const f3 u = tileClamp(uvw);
     const bool first = (u.x <= 0.5f) == (u.y <= 0.5f);
@@ -127,7 +132,7 @@ __device__ __forceinline__ f3 textureSample(const TexTables &tt, const qa_textur
   }
   const int width = tx.width, height = tx.height;
   if (width + height == 0) return F3(0, 0, 0);
-  const unsigned char *data = tt.blob + tx.off_texels;
+  const float4 *data = tt.texels + tt.texOff[ti];
   const f3 u = tileClamp(F3(uvw.x, 1.f - uvw.y, uvw.z));
   const float x = width * u.x, y = height * u.y;
   int ix = (int) x, iy = (int) y;
@@ -140,21 +145,21 @@ __device__ __forceinline__ f3 textureSample(const TexTables &tt, const qa_textur
   if (iy >= height) iy -= (iy / height) * height;
   int iyp = iy + 1;
   if (iyp >= height) iyp -= height;
-  f3 r = texel(data + 3 * (iy * width + ix)) * ((1 - fx) * (1 - fy));
-  r = r + texel(data + 3 * (iy * width + ixp)) * (fx * (1 - fy));
-  r = r + texel(data + 3 * (iyp * width + ix)) * ((1 - fx) * fy);
-  r = r + texel(data + 3 * (iyp * width + ixp)) * (fx * fy);
+  f3 r = texel(data + (iy * width + ix)) * ((1 - fx) * (1 - fy));
+  r = r + texel(data + (iy * width + ixp)) * (fx * (1 - fy));
+  r = r + texel(data + (iyp * width + ix)) * ((1 - fx) * fy);
+  r = r + texel(data + (iyp * width + ixp)) * (fx * fy);
   return r;
 }
 
 // Texture::Sample(uvw, duvw, elliptic = true) (src/core/texture.cpp:32-52)
-__device__ __forceinline__ f3 textureSampleFiltered(const TexTables &tt, const qa_texture &tx, f3 uvw, f3 d0, f3 d1)
+__device__ __forceinline__ f3 textureSampleFiltered(const TexTables &tt, int ti, f3 uvw, f3 d0, f3 d1)
 {
-  f3 c = textureSample(tt, tx, uvw);
+  f3 c = textureSample(tt, ti, uvw);
   if (dot(d0, d0) + dot(d1, d1) == 0) return c;
   for (int i = 0; i < 31; ++i) {
     const float x = tt.filter[2 * i], y = tt.filter[2 * i + 1];
-    c = c + textureSample(tt, tx, (uvw + d0 * x) + d1 * y);
+    c = c + textureSample(tt, ti, (uvw + d0 * x) + d1 * y);
   }
   return c / 32.f;
 }
@@ -167,7 +172,7 @@ __device__ __forceinline__ f3 texColorSample(const TexTables &tt, f3 color, int 
   if (texmap < 0) return color;
   const qa_texmap &m = tt.texmap[texmap];
   if (m.texture < 0) return color * F3(0, 0, 0);
-  return color * textureSample(tt, tt.tex[m.texture], xformTo(m, uvw));
+  return color * textureSample(tt, m.texture, xformTo(m, uvw));
 }
 
 // static Sample(hInfo, TexturedColor) (src/materials/MtlBlinn_PhotonMap.cpp:34-39) over
@@ -180,7 +185,7 @@ __device__ __forceinline__ f3 mtlSample(const TexTables &tt, const TexHit &h, f3
   const f3 u = xformTo(m, h.uvw);
   const f3 d0 = xformTo(m, h.duvw0 + h.uvw) - u;
   const f3 d1 = xformTo(m, h.duvw1 + h.uvw) - u;
-  return color * textureSampleFiltered(tt, tt.tex[m.texture], u, d0, d1);
+  return color * textureSampleFiltered(tt, m.texture, u, d0, d1);
 }
 
 // TexturedColor::SampleEnvironment (src/core/texture.cpp:106-114)

@@ -277,6 +277,8 @@ __device__ __forceinline__ WfEmit wfLogicSlot(const DScene &sc, const RenderPara
     const WfPixel px = wfPixel(rp, b, slot);
     TexTables tt;
     tt.blob = sc.blob;
+    tt.texels = sc.texels;
+    tt.texOff = sc.texOff;
     tt.texmap = sc.texmap;
     tt.tex = sc.tex;
     tt.filter = sc.texFilter;

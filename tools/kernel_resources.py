@@ -43,7 +43,8 @@ def main():
         i = args.index("--grep")
         pat = args[i + 1]
         del args[i:i + 2]
-    objs = args or [os.path.join(ROOT, "qaray_amd", "lib", "obj", f) for f in sorted(os.listdir(os.path.join(ROOT, "qaray_amd", "lib", "obj")))]
+    objs = args or [os.path.join(ROOT, "qaray_amd", "lib", "obj", f) for f in sorted(os.listdir(os.path.join(ROOT, "qaray_amd", "lib", "obj")))
+                    if f.endswith(".o") and "-hip-" not in f and "-host-" not in f]   # (the objects, not the compiler temporaries next to them)
     for obj in objs:
         ks = kernels_of(obj)
         names = demangle([k["name"] for k in ks])
