@@ -78,7 +78,7 @@ static const char *kStagedName = "staged: wf_logic + wf_cull + wf_trace + wf_red
 static std::string MegaName(const qa_ctx *c, bool cs)
 {
   char name[160];
-  if (cs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d,CULL=%d>", (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->csCullVariant);
+  if (cs) snprintf(name, sizeof(name), "qa_integrate_cs<LIGHTS=%d,TEX=%d,CULL=%d%s>", (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->csCullVariant, c->area ? ",AREA=1" : "");
   else snprintf(name, sizeof(name), "qa_integrate<RES=%d,LIGHTS=%d,TEX=%d,AREA=%d>", (int) c->resident, (int) (c->ds.num_lights > 0), (int) c->textured, (int) c->area);
   return name;
 }
@@ -108,7 +108,7 @@ static int SelectKernel(qa_ctx *c)
   c->blocksPerCUAuto = resident > 8 ? 8 : resident;
   // Cooperative mesh walks (qa_kernel_cs.h): scenes in global memory without area lights.  QA_COOP=0: off.
   // (any number of lights: their shadow queries are pooled QA_CS_LIGHT_BATCH = 4 lights at a time; with more than one batch the
-  // surface waits in the slab DScene::csSurf between batches, qa_kernel_cs.h)
+  // surface waits in the slab DScene::csSurf between batches, qa_kernel_cs.h; area lights: the AREA variants)
   c->kernelCs = nullptr;
   {
     const char *e = DevEnv("QA_COOP");
@@ -118,13 +118,15 @@ static int SelectKernel(qa_ctx *c)
       const qa_light *hl = QA_BLOB_PTR(qa_light, c->hostBlob.data(), fh->off_lights);
       for (uint32_t i = 0; i < fh->num_lights; ++i) shadowLights += hl[i].type != QA_LIGHT_AMBIENT;
     }
-    if (!c->resident && !c->area && c->csFits && (shadowLights <= QA_CS_LIGHT_BATCH || c->ds.csSurf) && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
+    if (!c->resident && c->csFits && (shadowLights <= QA_CS_LIGHT_BATCH || c->ds.csSurf) && c->ldsBytesCs <= kMaxLdsPerBlock && c->optCoop && !(e && !strcmp(e, "0"))) {
       // instance culling (qa_kernel_cs.h): the textured variants always (it pays from a handful of nodes on: C3, 9 nodes, + 4 %), the
       // untextured ones on scenes of more than 12 nodes (their register budget: see the kernel's comment)
       c->csCullVariant = c->csCullOk && (c->textured || c->ds.num_inst > 12);
-      const bool many = shadowLights > QA_CS_LIGHT_BATCH;   // (those variants always test the nodes' bounds)
-      if (many) c->csCullVariant = c->csCullOk;
-      if (many)
+      const bool many = shadowLights > QA_CS_LIGHT_BATCH && !c->area;   // (those variants always test the nodes' bounds)
+      if (many || c->area) c->csCullVariant = c->csCullOk;
+      if (c->area)   // every light is evaluated when the path has ended, by the whole wave (qa_kernel_cs.h, AREA)
+        c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true, true, true, false, true> : (KernelFn) qa_integrate_cs<true, false, true, false, true>;
+      else if (many)
         c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true, true, true, true> : (KernelFn) qa_integrate_cs<true, false, true, true>;
       else if (c->csCullVariant)
         c->kernelCs = lights ? (c->textured ? (KernelFn) qa_integrate_cs<true, true, true, false> : (KernelFn) qa_integrate_cs<true, false, true, false>)
@@ -889,6 +891,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   rp.seed = seed;
   rp.tile_row0 = tile_row0; rp.tile_row_step = tile_row_step; rp.own_tile_rows = ownRows; rp.pad = 0;
   rp.sync_samples = c->syncSamples < 0 ? c->syncAuto : c->syncSamples;
+  if (c->kernelCs && c->area) rp.sync_samples = 1;   // the cooperative AREA variants evaluate a wave's lights between its samples
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
   rp.tile_order = nullptr;

@@ -742,6 +742,59 @@ __device__ __forceinline__ void csShadowRay(const qa_light &l, f3 p, Ray &w, flo
   }
 }
 
+// The sweep of ONE shadow ray per lane (slot jj of the running batch: nb slots so far) over the scene graph: spheres and planes on the
+// spot, meshes into the pool; the pool runs in between only when it cannot take an instance's rays.
+template <bool CULL>
+__device__ __forceinline__ void csShadowSweep(const DScene &sc, const CsLds &L, bool lit, const Ray &w, float tmax, uint32_t jj, uint32_t nb, uint32_t &occl,
+                                              uint32_t &redo, uint32_t &n, uint32_t &nSlots, DCounters &cnt)
+{
+  cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
+  const Ray r0 = rootRay<false>(sc, w);
+  GroupRay grp;
+  grp.node = -1;
+  grp.ray = r0;
+  const CsCullRay cull = csCullRay(sc, r0);
+  for (int k = 1; k < sc.num_inst; ++k) {
+    bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
+    if (!__any(open)) break;                             // settled for the whole wave: next ray
+    if (CULL && sc.csCullOn) {
+      open = open && csCullPass(ldTable(sc.csCull + k), cull, r0.p, tmax);   // ... and its ray can meet node k's object
+      if (!__any(open)) continue;
+    }
+    const CsInst ci = ldTable(sc.csInst + k);
+    const int type = ci.type;
+    if (type == QA_OBJ_NONE) continue;
+    const Ray r = csLocalSweep(ci, r0, grp);
+    if (type != QA_OBJ_MESH) {
+      Hit hh;
+      hh.z = tmax;
+      hh.node = -1;
+      const bool hit = open && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, false) : hitPlane(r, hh, k, false));
+      if (hit) occl |= 1u << jj;
+      continue;
+    }
+    const bool go = open && csGate(ci, r, tmax);
+    bool coop = go && ci.useWide && insideCancelReach(ci, r.p);
+    if (go && !coop) redo |= 1u << jj;
+    unsigned long long mk = __ballot(coop);
+    uint32_t c = (uint32_t) __popcll(mk);
+    if (!c) continue;
+    // (rarely: see csTraceClosest)
+    if (__builtin_expect(nSlots + c > L.slots || n + c > L.capItems, 0)) {
+      csRun<false>(sc, L, n, QA_FILL(cnt));
+      csSettleShadows(sc, L, nb, occl, redo);   // before the slots are reused
+      nSlots = 0;
+      coop = coop && !(((occl | redo) >> jj) & 1u);   // queries that run decided do not enter
+      mk = __ballot(coop);
+      c = (uint32_t) __popcll(mk);
+      if (!c) continue;
+    }
+    csEnter(L, mk, coop, r, tmax, jj, csPad(ci, r.p), ci.csRootWord, n, nSlots);
+    n += c;
+    nSlots += c;
+  }
+}
+
 // GenLight::Shadow -> Scene::TraceNodeShadow for the next batch of up to QA_CS_LIGHT_BATCH non-ambient lights (table index li
 // onwards; on return li is where the following batch starts and nb the lights taken), for the lanes with `lit`: bit jj of the
 // result = light jj of the batch occluded.  The reference stops at the first node that occludes; which one does not matter.
@@ -763,51 +816,7 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
     Ray w;
     float tmax;
     csShadowRay(l, p, w, tmax);
-    cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
-    const Ray r0 = rootRay<false>(sc, w);
-    GroupRay grp;
-    grp.node = -1;
-    grp.ray = r0;
-    const CsCullRay cull = csCullRay(sc, r0);
-    for (int k = 1; k < sc.num_inst; ++k) {
-      bool open = lit && !(((occl | redo) >> jj) & 1u);   // this lane's query is still undecided
-      if (!__any(open)) break;                             // settled for the whole wave: next light
-      if (CULL && sc.csCullOn) {
-        open = open && csCullPass(ldTable(sc.csCull + k), cull, r0.p, tmax);   // ... and its ray can meet node k's object
-        if (!__any(open)) continue;
-      }
-      const CsInst ci = ldTable(sc.csInst + k);
-      const int type = ci.type;
-      if (type == QA_OBJ_NONE) continue;
-      const Ray r = csLocalSweep(ci, r0, grp);
-      if (type != QA_OBJ_MESH) {
-        Hit hh;
-        hh.z = tmax;
-        hh.node = -1;
-        const bool hit = open && (type == QA_OBJ_SPHERE ? hitSphere(r, hh, k, false) : hitPlane(r, hh, k, false));
-        if (hit) occl |= 1u << jj;
-        continue;
-      }
-      const bool go = open && csGate(ci, r, tmax);
-      bool coop = go && ci.useWide && insideCancelReach(ci, r.p);
-      if (go && !coop) redo |= 1u << jj;
-      unsigned long long mk = __ballot(coop);
-      uint32_t c = (uint32_t) __popcll(mk);
-      if (!c) continue;
-      // (rarely: see csTraceClosest)
-      if (__builtin_expect(nSlots + c > L.slots || n + c > L.capItems, 0)) {
-        csRun<false>(sc, L, n, QA_FILL(cnt));
-        csSettleShadows(sc, L, nb, occl, redo);   // before the slots are reused
-        nSlots = 0;
-        coop = coop && !(((occl | redo) >> jj) & 1u);   // queries that run decided do not enter
-        mk = __ballot(coop);
-        c = (uint32_t) __popcll(mk);
-        if (!c) continue;
-      }
-      csEnter(L, mk, coop, r, tmax, jj, csPad(ci, r.p), ci.csRootWord, n, nSlots);
-      n += c;
-      nSlots += c;
-    }
+    csShadowSweep<CULL>(sc, L, lit, w, tmax, jj, nb, occl, redo, n, nSlots, cnt);
   }
   if (n != 0) {
     csRun<false>(sc, L, n, QA_FILL(cnt));
@@ -834,6 +843,47 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
     }
   }
   return occl;
+}
+
+// The same for up to four GIVEN shadow rays per lane from one origin (directions normalised, slot s for the lanes with bit s of
+// `mask`): the samples of an area light (AREA variants).  Bit s of the result = ray s occluded.
+struct CsRays4 { f3 d0, d1, d2, d3; float t0, t1, t2, t3; };
+template <bool CULL>
+__device__ __forceinline__ uint32_t csShadowRays(const DScene &sc, const CsLds &L, uint32_t mask, uint32_t nrays, f3 p, const CsRays4 &q, DCounters &cnt)
+{
+  const unsigned lane = __lane_id();
+  uint32_t occl = 0, redo = 0;
+  for (uint32_t jj = 0; jj < QA_CS_LIGHT_BATCH; ++jj) L.res[jj * 64u + lane] = 0;
+  L.flags[lane] = 0;
+  uint32_t n = 0, nSlots = 0;
+#define QA_CS_RAY(S, D, T)                                                                            \
+  if (nrays > S) {                                                                                    \
+    Ray w;                                                                                            \
+    w.p = p;                                                                                          \
+    w.d = D;                                                                                          \
+    csShadowSweep<CULL>(sc, L, ((mask >> S) & 1u) != 0, w, T, S, S + 1u, occl, redo, n, nSlots, cnt); \
+  }
+  QA_CS_RAY(0u, q.d0, q.t0)
+  QA_CS_RAY(1u, q.d1, q.t1)
+  QA_CS_RAY(2u, q.d2, q.t2)
+  QA_CS_RAY(3u, q.d3, q.t3)
+#undef QA_CS_RAY
+  if (n != 0) {
+    csRun<false>(sc, L, n, QA_FILL(cnt));
+    csSettleShadows(sc, L, nrays, occl, redo);
+  }
+  if (sc.csForceExact & 2u) { occl = 0; redo = mask; }
+  redo &= ~occl & mask;
+  if (__any(redo != 0)) {
+#define QA_CS_REDO(S, D, T)                                                                                                                            \
+    if (((redo >> S) & 1u) && csExactShadow(sc.inst, sc.mesh, sc.num_inst, sc.rootIdentity, p.x, p.y, p.z, D.x, D.y, D.z, T)) occl |= 1u << S;
+    QA_CS_REDO(0u, q.d0, q.t0)
+    QA_CS_REDO(1u, q.d1, q.t1)
+    QA_CS_REDO(2u, q.d2, q.t2)
+    QA_CS_REDO(3u, q.d3, q.t3)
+#undef QA_CS_REDO
+  }
+  return occl & mask;
 }
 
 // One light's term of MtlBlinn_PhotonMap::Shade's light loop (directLight of qa_kernel.h) with the shadow factor known
@@ -924,7 +974,13 @@ __host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) {
 // (C4, 10 nodes: 4 530 without the code, 4 010 with it; a field of 38 nodes: 1 470 -> 2 100 Msamples/s): qa_capi.hip SelectKernel.
 // MANY: more shadow-casting lights than one batch (QA_CS_LIGHT_BATCH): the surface is parked in DScene::csSurf and the further
 // batches follow.  A variant of its own for the same reason: with that loop compiled in, scenes of one batch lose 6 - 11 %.
-template <bool LIGHTS, bool TEX, bool CULL, bool MANY>
+// AREA: scenes with area lights (point / spot lights with a size: 16 - 64 shadow rays per evaluation, src/lights/lights.cpp:52-65).
+// Their samples draw random numbers, and the reference evaluates a hit's lights only after the whole recursive subtree below it
+// (qa_kernel.h, AREA variants): every lit hit is logged (19 floats per hit in DScene::areaScratch) and ALL lights are evaluated when
+// the path has ended, deepest hit first - here by the whole wave at once: the lanes of a wave wait for each other between samples
+// (sync_samples is forced), the log is replayed level by level, and an area light's samples are walked four shadow rays per lane at a
+// time from the pool (csShadowRays) - exactly the any-hit batches the pool wants.
+template <bool LIGHTS, bool TEX, bool CULL, bool MANY, bool AREA = false>
 __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX) void qa_integrate_cs(const DScene sc, const RenderParams rp)
 {
   extern __shared__ uint4 s_dyn[];
@@ -974,6 +1030,8 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   f3 pT = F3(0, 0, 0), pL = F3(0, 0, 0);
   uint32_t pst = QA_PST_PRIMARY;
   bool alive = true, needPixel = true, needSample = false;
+  uint32_t nrec = 0;       // AREA: hits logged for the current path
+  bool awaiting = false;   // AREA: the path has ended, its lights have not been evaluated yet
 
   for (;;) {
     QA_T(tA)
@@ -1034,7 +1092,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     }
     QA_TACC(cnt.sl[1], tA)
     // ---- C. trace (qa_integrate, section C)
-    const bool act = alive && !needPixel && !needSample;
+    const bool act = alive && !needPixel && !needSample && !(AREA && awaiting);
     bool done = false;
     Hit h;
     TexHit th;
@@ -1104,7 +1162,17 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     CsTerms terms;
     terms.c0 = terms.c1 = terms.c2 = terms.c3 = F3(0, 0, 0);
     f3 litT = F3(0, 0, 0);
-    if (LIGHTS) {
+    if (AREA) {
+      // log the hit: position, normal, view direction, throughput, sampled colours, glossiness (qa_kernel.h's record)
+      if (lit && nrec < QA_MAX_PATH) {
+        const size_t stride = (size_t) gridDim.x * QA_BLOCK;
+        float *rec = sc.areaScratch + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x + (size_t) nrec * QA_REC_FLOATS * stride;
+        const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, pT.x, pT.y, pT.z, sf.kd.x, sf.kd.y, sf.kd.z, sf.ks.x, sf.ks.y, sf.ks.z, sf.gloss};
+#pragma unroll
+        for (int f = 0; f < QA_REC_FLOATS; ++f) rec[(size_t) f * stride] = v[f];
+        ++nrec;
+      }
+    } else if (LIGHTS) {
       if (__any(lit)) {
         QA_T(tLt)
         terms = csLightTerms(sc, lit, 0, p, N, V, sf.kd, sf.ks, sf.gloss);
@@ -1132,7 +1200,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       }
     }
     // ---- second half: the whole wave walks the shadow rays of its lit lanes
-    if (LIGHTS) {
+    if (LIGHTS && !AREA) {
       if (__any(lit)) {
         QA_T(tL)
         int li = 0;
@@ -1159,6 +1227,106 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       }
     }
 
+    // ---- AREA: the lights of the paths that have ended, once the whole wave is between samples
+    if (AREA) {
+      awaiting = awaiting || (alive && done);
+      done = false;
+      if (__any(awaiting) && __ballot(awaiting) == __ballot(alive && !needPixel)) {
+        QA_T(tL)
+        uint32_t maxrec = 0;
+        for (uint32_t b = 0; b < 4u; ++b) if (__any(awaiting && ((nrec >> b) & 1u))) maxrec |= 1u << b;   // (an upper bound of the wave's deepest log)
+        const size_t stride = (size_t) gridDim.x * QA_BLOCK;
+        const float *rec0 = sc.areaScratch + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x;
+        const float normCoefDI = 1.f / (float) sc.num_lights;
+        for (uint32_t lvl = maxrec < QA_MAX_PATH ? maxrec : QA_MAX_PATH; lvl-- > 0;) {
+          const bool on = awaiting && nrec > lvl;
+          if (!__any(on)) continue;
+          float v[QA_REC_FLOATS];
+#pragma unroll
+          for (int f = 0; f < QA_REC_FLOATS; ++f) v[f] = on ? rec0[((size_t) lvl * QA_REC_FLOATS + f) * stride] : 0.f;
+          const f3 hp = F3(v[0], v[1], v[2]), hN = F3(v[3], v[4], v[5]), hV = F3(v[6], v[7], v[8]);
+          f3 sum = F3(0, 0, 0);
+          // directLight + illuminate of qa_kernel.h, the shadow queries done by the wave
+          for (int li = 0; li < sc.num_lights; ++li) {
+            const qa_light l = ldTable(sc.light + li);
+            if (l.type == QA_LIGHT_AMBIENT) continue;
+            f3 I;
+            if (l.type != QA_LIGHT_DIRECT && l.size > 0.01f) {
+              // area light: 16 shadow rays towards points of a ball around the light, 64 as soon as the running estimate is a
+              // penumbra value (src/lights/lights.cpp:52-65,88-100) - four at a time: the first 16 always exist, and whether the
+              // other 48 do is decided by then
+              int spp = 16, ns = 0;
+              float inshadow = 0.0f;
+              for (;;) {
+                const bool more = on && ns < spp;
+                if (!__any(more)) break;
+                CsRays4 q;
+                f3 dir0 = F3(0, 0, 1), dir1 = dir0, dir2 = dir0, dir3 = dir0;
+                if (more) {
+                  dir0 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
+                  dir1 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
+                  dir2 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
+                  dir3 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
+                }
+                q.d0 = normalize(dir0); q.t0 = length(dir0);
+                q.d1 = normalize(dir1); q.t1 = length(dir1);
+                q.d2 = normalize(dir2); q.t2 = length(dir2);
+                q.d3 = normalize(dir3); q.t3 = length(dir3);
+                const uint32_t occl = csShadowRays<CULL>(sc, L, more ? 15u : 0u, 4u, hp, q, cnt);
+                if (more) {
+#define QA_CS_FOLD(S, DIR)                                                                                                   \
+                  {                                                                                                            \
+                    const float shadowed = ((occl >> S) & 1u) ? 0.0f : 1.0f;                                                   \
+                    inshadow += (shadowed - inshadow) * inverseSquareFalloff(DIR) / (float) (ns + 1);                          \
+                    ns++;                                                                                                      \
+                    if (inshadow > 0.f && inshadow < 1.f) spp = 64;                                                            \
+                  }
+                  QA_CS_FOLD(0, dir0)
+                  QA_CS_FOLD(1, dir1)
+                  QA_CS_FOLD(2, dir2)
+                  QA_CS_FOLD(3, dir3)
+#undef QA_CS_FOLD
+                }
+              }
+              I = ld3(l.intensity) * inshadow;
+              if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, hp);
+            } else {
+              CsRays4 q;
+              q.d1 = q.d2 = q.d3 = F3(0, 0, 1);
+              q.t1 = q.t2 = q.t3 = 0.f;
+              f3 dir = F3(0, 0, 1);
+              if (l.type == QA_LIGHT_DIRECT) {
+                q.d0 = normalize(-ld3(l.direction));
+                q.t0 = QA_BIGFLOAT;
+              } else {
+                dir = ld3(l.position) - hp;
+                q.d0 = normalize(dir);
+                q.t0 = length(dir);
+              }
+              const uint32_t occl = csShadowRays<CULL>(sc, L, on ? 1u : 0u, 1u, hp, q, cnt);
+              const float shadowed = (occl & 1u) ? 0.0f : 1.0f;
+              if (l.type == QA_LIGHT_DIRECT) I = ld3(l.intensity) * shadowed;
+              else {
+                I = (ld3(l.intensity) * shadowed) * inverseSquareFalloff(dir);
+                if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, hp);
+              }
+            }
+            const f3 intensity = I * normCoefDI;
+            const f3 Ld = normalize(-lightDirection(l, hp));
+            const f3 H = normalize(hV + Ld);
+            const float cosNL = qmax(0.f, dot(hN, Ld));
+            const float cosNH = qmax(0.f, dot(hN, H));
+            const f3 brdf = F3(v[12], v[13], v[14]) + F3(v[15], v[16], v[17]) * qpowf(cosNH, v[18]);
+            sum = sum + (intensity * cosNL) * brdf;
+          }
+          if (on) pL = pL + F3(v[9], v[10], v[11]) * sum;
+        }
+        QA_TACC(cnt.sl[5], tL)
+        done = awaiting;
+        awaiting = false;
+        nrec = 0;
+      }
+    }
     // ---- E. sample finished (qa_integrate, section E; scene.cpp:92-121)
     bool pixelDone = false;
     if (alive && done) {

@@ -583,7 +583,7 @@ def test_cli_multi_device_path_equals_the_single_context_path(tmp_path, scene, s
     assert outs["single"] == outs["multi"]
 
 
-@pytest.mark.parametrize("case", ["box", "sphere_lights", "textures", "object", "tower", "caustics", "softshadow", "object_staged", "glass_photon"])
+@pytest.mark.parametrize("case", ["box", "sphere_lights", "textures", "object", "tower", "caustics", "softshadow", "area_coop", "object_staged", "glass_photon"])
 def test_frames_do_not_depend_on_stale_scratch(case):
     """The photon-walk nondeterminism of rounds 1 / 2 was hipcc storing a spill ahead of the instruction that re-enables masked
     lanes: the lanes that never stored reloaded whatever the scratch slot held.  Whatever the cause, such a read
@@ -597,7 +597,7 @@ def test_frames_do_not_depend_on_stale_scratch(case):
     scene, size, spp = {"box": ("example_project12_box.xml", (320, 180), 8), "sphere_lights": ("example_project3_sphere.xml", (256, 256), 4),
                         "textures": ("custom_textures.xml", (240, 180), 4), "object": ("example_project7_object.xml", (320, 180), 4),
                         "tower": ("trc_scene_tower.xml", (320, 180), 4), "caustics": ("example_project12_caustics_glossy.xml", (320, 180), 4),
-                        "softshadow": ("custom_softshadow.xml", (160, 120), 2), "object_staged": ("example_project7_object.xml", (240, 136), 2),
+                        "softshadow": ("custom_softshadow.xml", (160, 120), 2), "area_coop": ("example_project10_test.xml", (160, 120), 2), "object_staged": ("example_project7_object.xml", (240, 136), 2),
                         "glass_photon": ("trc_mtl_glass.xml", (96, 72), 2)}[case]
     c = hip.Context(0)
     c.upload_scene(load_scene_blob(scene, size=size))

@@ -333,6 +333,65 @@ def test_exact_walks_alone_return_the_frame(scene):
     c.close()
 
 
+def _write_area_lights_scene(path):
+    """Two global-memory mesh instances, a sphere and a floor under an area point light, an area spot light, a plain point light and a
+    direct light: every branch of the AREA variants' light replay."""
+    open(path, "w").write(
+        '<xml><scene>'
+        '<object type="plane" name="floor" material="white"><scale value="40"/></object>'
+        '<object type="obj" name="teapot-high.obj" material="red"><scale value="0.6"/><rotate angle="-40" z="1"/><translate x="-4" y="0" z="0"/></object>'
+        '<object type="obj" name="teapot-high.obj" material="glass"><scale value="0.4"/><rotate angle="70" z="1"/><translate x="6" y="-3" z="0"/></object>'
+        '<object type="sphere" name="ball" material="glossy"><scale value="2.5"/><translate x="2" y="6" z="2.5"/></object>'
+        '<material type="blinn" name="white"><diffuse r="0.8" g="0.8" b="0.8"/><specular value="0"/></material>'
+        '<material type="blinn" name="red"><diffuse r="0.8" g="0.2" b="0.2"/><specular value="0.5"/><glossiness value="30"/></material>'
+        '<material type="blinn" name="glass"><diffuse value="0.05"/><specular value="0.8"/><glossiness value="60"/><refraction value="0.9" index="1.5"/></material>'
+        '<material type="blinn" name="glossy"><diffuse r="0.2" g="0.3" b="0.8"/><specular value="0.7"/><glossiness value="20"/><reflection value="0.5" glossiness="0.05"/></material>'
+        '<light type="ambient" name="amb"><intensity value="0.1"/></light>'
+        '<light type="point" name="area"><intensity value="60"/><position x="0" y="-8" z="14"/><size value="2.5"/></light>'
+        '<light type="spot" name="areaspot"><intensity value="90"/><position x="-10" y="6" z="12"/><rotation angle="50" x="1" y="1" z="0"/><angle value="55"/><blend value="0.3"/><size value="1.2"/></light>'
+        '<light type="point" name="hard"><intensity value="25"/><position x="9" y="9" z="10"/></light>'
+        '<light type="direct" name="sun"><intensity value="0.3"/><direction x="0.4" y="0.3" z="-1"/></light>'
+        '</scene><camera><position x="0" y="-32" z="14"/><target x="0" y="0" z="2"/><up x="0" y="0" z="1"/><fov value="40"/><width value="800"/><height value="600"/></camera></xml>')
+
+
+@pytest.mark.parametrize("case", ["project10_test", "every_light_kind"])
+def test_cooperative_area_lights_equal_the_per_lane_kernel(tmp_path, case):
+    """Area lights over global-memory meshes: qa_integrate_cs<..., AREA=1> logs every lit hit and evaluates all lights when the path
+    has ended, the whole wave walking an area light's 16 - 64 sample rays four per lane at a time from the pool.  Same bits, sample
+    counts, depth and cast counters as qa_integrate's AREA variant (every lane walks its own rays; option "coop" = 0), and the
+    oracle's casts / depth / radiance."""
+    from oracle import binding as oracle
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    if case == "project10_test":
+        size, spp = (200, 150), 2
+        blob = load_scene_blob("example_project10_test.xml", size=size)
+    else:
+        xml = str(tmp_path / "area_lights.xml")
+        _write_area_lights_scene(xml)
+        size, spp = (160, 120), 2
+        blob = load_scene_blob(xml, size=size, asset_root=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes"))
+    w, h = size
+    outs, cnts = {}, {}
+    for mode in ("coop", "own"):
+        c = hip.Context(0)
+        c.set_option("coop", 1 if mode == "coop" else 0)
+        c.upload_scene(blob)
+        assert ("qa_integrate_cs" in c.kernel_name() and "AREA=1" in c.kernel_name()) == (mode == "coop"), c.kernel_name()
+        c.reset_counters()
+        outs[mode] = c.render_region((0, 0, w, h), spp)
+        cnts[mode] = c.counters()
+        c.close()
+    for a, b in zip(outs["coop"], outs["own"]):
+        assert np.array_equal(bits(a), bits(b))
+    assert cnts["coop"] == cnts["own"]
+    o = oracle.render(blob, (0, 0, w, h), spp)
+    assert np.array_equal(bits(outs["coop"][1]), bits(o[1])) and np.array_equal(outs["coop"][2], o[2])
+    assert (cnts["coop"]["casts_normal"], cnts["coop"]["casts_shadow"]) == (o[3].casts_normal, o[3].casts_shadow)
+    assert rmse(np.nan_to_num(outs["coop"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
+
+
 def test_exact_repeat_is_exercised_and_invisible(ctx, tmp_path):
     """Coincident sheets: the staged integrator must send rays to wf_redo (ties / failed order checks) - and the frame
     must not show it."""
