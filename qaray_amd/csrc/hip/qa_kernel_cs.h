@@ -28,6 +28,10 @@
 // the lane's query to the exact sequential walk of the whole scene graph on the reference's trees (csExactClosest /
 // csExactShadow: out of line, private stacks - a handful of rays per million).  Shading and every random draw are
 // qa_integrate's: frames are bit-identical.
+// Kernel variants (template parameters; why they are variants and not branches: DESIGN.md 4d / 5 round 3 - every live value more
+// in the sweeps is paid in spilled registers): CULL - the sweeps test a node's root-space bounds first and skip nodes no lane of
+// the wave can meet; MANY - more than four shadow-casting lights, in batches of four with the surface parked in a global slab;
+// AREA - area lights: hit log, all lights evaluated by the whole wave when its paths have ended, sample rays four per lane at a time.
 //
 // Replaces (reference file:line): Scene::TraceNodeNormal / TraceNodeShadow (src/scene/scene.cpp:35-74), GenLight::Shadow
 // (src/lights/lights.cpp:39-48), TriObj::IntersectRay / TraceBVHNode (src/objects/objects.cpp:310-420); everything else as qa_kernel.h.
