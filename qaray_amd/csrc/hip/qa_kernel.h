@@ -1061,31 +1061,38 @@ __device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const S &
     f3 sampleSpecular = F3(asF(m1.x), asF(m1.y), asF(m1.z));
     const float glossSpec = asF(m1.w);
     f3 emission = F3(asF(m2.x), asF(m2.y), asF(m2.z));
-    int4 mtex0 = make_int4(-1, -1, -1, -1);  // texmaps: diffuse, specular, emission, reflection
-    int mtex4 = -1;                          //          refraction
-    if (TEX) {
-      const int *mt = sc.mtlTex + 8 * (size_t) mi;
-      mtex0 = make_int4(mt[0], mt[1], mt[2], mt[3]);
-      mtex4 = mt[4];
-      emission = mtlSample(tt, th, emission, mtex0.z);
-    }
     const uint32_t mflags = m5.w;
-        const f3 Y = dot(N, V) > 0.f ? N : -N;
-    
+    f3 rK = F3(0, 0, 0), tK = F3(0, 0, 0);
+    float glossRefl = 0.f, glossRefr = 0.f;
+    if (mflags & QA_MTL_SPECULAR_LOBES) {
+      const uint4 m3 = mr[3], m4 = mr[4];
+      rK = F3(asF(m3.x), asF(m3.y), asF(m3.z));
+      tK = F3(asF(m4.x), asF(m4.y), asF(m4.z));
+      glossRefl = asF(m3.w);
+      glossRefr = asF(m4.w);
+    }
+    if (TEX) {
+      // Every texture lookup of the hit FIRST (the reference samples the colours where it uses them, MtlBlinn_PhotonMap.cpp:262-330;
+      // the lookups are pure functions of the hit, so their place does not show): the 32-tap loops then run with nothing of the
+      // Fresnel / lobe arithmetic alive beside them - they are where the textured kernels spill.
+      const int *mt = sc.mtlTex + 8 * (size_t) mi;   // texmaps: diffuse, specular, emission, reflection, refraction
+      const int4 mtex0 = make_int4(mt[0], mt[1], mt[2], mt[3]);
+      const int mtex4 = mt[4];
+      emission = mtlSample(tt, th, emission, mtex0.z);
+      if (mflags & QA_MTL_SPECULAR_LOBES) {
+        tK = mtlSample(tt, th, tK, mtex4);
+        rK = mtlSample(tt, th, rK, mtex0.w);
+      }
+      sampleSpecular = mtlSample(tt, th, sampleSpecular, mtex0.y);
+      sampleDiffuse = mtlSample(tt, th, sampleDiffuse, mtex0.x);
+    }
+    const f3 Y = dot(N, V) > 0.f ? N : -N;
+
     // ComputeFresnel (:65-105); skipped when neither lobe can receive energy: with
     // tK = rK = 0 both products below are exactly 0 for any finite Fresnel term.
     f3 sampleTransmission = F3(0, 0, 0), sampleReflection = F3(0, 0, 0);
     f3 tDir = F3(0, 0, 0), rDir = F3(0, 0, 0);
-    float glossRefl = 0.f, glossRefr = 0.f;
     if (mflags & QA_MTL_SPECULAR_LOBES) {
-      const uint4 m3 = mr[3], m4 = mr[4];
-      f3 rK = F3(asF(m3.x), asF(m3.y), asF(m3.z)), tK = F3(asF(m4.x), asF(m4.y), asF(m4.z));
-      if (TEX) {
-        tK = mtlSample(tt, th, tK, mtex4);
-        rK = mtlSample(tt, th, rK, mtex0.w);
-      }
-      glossRefl = asF(m3.w);
-      glossRefr = asF(m4.w);
       const float ior = asF(m2.w);
       const f3 Z = cross(V, Y);
       const f3 X = normalize(cross(Y, Z));
@@ -1104,10 +1111,6 @@ __device__ __forceinline__ Surface shadeSurface(const uint4 *mtlTable, const S &
       sampleReflection = totReflection ? (rK + tK) : (rK + tK * rC);
     }
 
-    if (TEX) {
-      sampleSpecular = mtlSample(tt, th, sampleSpecular, mtex0.y);
-      sampleDiffuse = mtlSample(tt, th, sampleDiffuse, mtex0.x);
-    }
     // RandomSelectMtl (:107-150): one draw, luma-weighted lobes + Russian roulette
     const float lumaT = luma(sampleTransmission), lumaR = luma(sampleReflection), lumaD = luma(sampleDiffuse);
     const float rsel = rng1(rng);
