@@ -177,7 +177,7 @@ def other_config(ctx, tag, args, torch, hip, qd, load_scene_blob, SCENES_DIR, de
     out = {"workload": f"inputs/{cfg['scene']} ({cfg['what']}), {W}x{H}, {spp} spp", "steps": 1,
            "value": cnt["samples"] / elapsed * 1e-6, "unit": "Msamples/s", "ms_per_step": elapsed * 1e3,
            "casts_per_sample": casts / max(cnt["samples"], 1),
-           "roofline": {"bound": "latency (see actual_limiter of the headline entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "latency (waves wait 36 - 54 % of their time at ~40 % VALU issue: profiles/round03/sq_hbm_counters_16spp.txt, DESIGN.md 5 round 3)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name, "kernel_ms_avg": k_ms / max(launches, 1),
                         "algorithmic_bytes_per_launch": k_bytes}}
     best = committed_traffic(kernel_name, cfg["scene"], W, H, spp)
@@ -355,8 +355,9 @@ def main():
             limiter = ("latency of the LDS-resident tree walk (53 % of wave time on the Cornell box at 5 waves/SIMD; all correctly rounded div / sqrt "
                        "removed: +5.5 % only); not HBM bandwidth (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
         elif "qa_integrate_cs" in kernel_name:
-            limiter = ("mesh walks of the whole wave from a pool of (ray, node) items in LDS (latency of dependent node reads, ds_bpermute ray "
-                       "fetches) and the scene-graph loop; not HBM bandwidth, not arithmetic (DESIGN.md 4d, profiles/round02/session3_experiments.txt)")
+            limiter = ("latency: waves wait 36 - 54 % of their time (dependent node / ray-slot reads of the cooperative walks, the scene-graph sweeps' "
+                       "scalar loads, reloads of spilled registers) at ~40 % VALU issue; what the spilled registers cost once they leave the L2 is the "
+                       "first-order effect (DESIGN.md 5 round 3, profiles/round03/experiments.txt, sq_hbm_counters_16spp.txt); not HBM bandwidth")
         else:
             limiter = ("mesh walks in global memory at low lane occupancy and the dependent loads of the scene-graph loop; not HBM bandwidth, not "
                        "arithmetic (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")

@@ -45,3 +45,9 @@ def test_headline_kernel_keeps_its_register_budget():
     assert line, out[-2000:]
     vgpr, agpr, sgpr, vspill = (int(x) for x in line[0].split()[:4])
     assert vgpr <= 96 and vspill <= 90, line[0]
+    # the cooperative kernels of BASELINE C4 / C5 and C3: their scratch must keep fitting the L2 (C4) / not grow
+    for name, limit in (("qa::qa_integrate_cs<true, false, false, false, false>", 80), ("qa::qa_integrate_cs<true, true, true, false, false>", 235)):
+        line = [l for l in out.splitlines() if l.rstrip().endswith(name)]
+        assert line, name
+        vgpr, agpr, sgpr, vspill = (int(x) for x in line[0].split()[:4])
+        assert vgpr <= 128 and vspill <= limit, line[0]
