@@ -392,6 +392,38 @@ def test_cooperative_area_lights_equal_the_per_lane_kernel(tmp_path, case):
     assert rmse(np.nan_to_num(outs["coop"][0]), np.nan_to_num(o[0])) <= RMSE_TOL
 
 
+def test_many_lights_on_a_textured_scene(tmp_path):
+    """project7_object with four more point lights (six shadow-casting lights: two batches): the textured MANY variant parks the surface
+    in the slab between the batches.  Same bits and counters as the per-lane kernel."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    scenes = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
+    txt = open(os.path.join(scenes, "example_project7_object.xml")).read()
+    lights = "".join('<light type="point" name="p%d"><intensity value="%g"/><position x="%g" y="%g" z="%g"/></light>\n' %
+                     (i, 0.3 + 0.1 * i, 30 * np.cos(1.1 * i), -20 + 25 * np.sin(0.9 * i), 25 + 3 * i) for i in range(4))
+    assert '<light type="direct"' in txt
+    txt = txt.replace('<light type="direct"', lights + '<light type="direct"', 1)
+    xml = str(tmp_path / "object_six_lights.xml")
+    open(xml, "w").write(txt)
+    w, h, spp = 240, 136, 2
+    blob = load_scene_blob(xml, size=(w, h), asset_root=scenes)
+    outs, cnts = {}, {}
+    for mode in ("coop", "own"):
+        c = hip.Context(0)
+        c.set_option("coop", 1 if mode == "coop" else 0)
+        c.upload_scene(blob)
+        assert ("qa_integrate_cs" in c.kernel_name() and "TEX=1" in c.kernel_name()) == (mode == "coop"), c.kernel_name()
+        c.reset_counters()
+        outs[mode] = c.render_region((0, 0, w, h), spp)
+        cnts[mode] = c.counters()
+        c.close()
+    for a, b in zip(outs["coop"], outs["own"]):
+        assert np.array_equal(bits(a), bits(b))
+    assert cnts["coop"] == cnts["own"]
+    assert cnts["coop"]["casts_shadow"] > 0
+
+
 def test_exact_repeat_is_exercised_and_invisible(ctx, tmp_path):
     """Coincident sheets: the staged integrator must send rays to wf_redo (ties / failed order checks) - and the frame
     must not show it."""
