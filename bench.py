@@ -184,6 +184,7 @@ def other_config(ctx, tag, args, torch, hip, qd, load_scene_blob, SCENES_DIR, de
     if best:
         out["roofline"]["traffic"] = best[0]["hbm_traffic_bytes_per_launch"]
         out["roofline"]["traffic_source"] = best[1]
+    add_compute_side(out["roofline"], cfg["scene"], W, H, spp)   # SQ passes of the same frame, when committed: sets 'bound' from the counters
     add_compute_side(out["roofline"], cfg["scene"], W, H, spp)
     if args.cpu_spp > 0:
         out["cpu_baseline"] = cpu_baseline(scene_xml, W, H, CPU_SAMPLE_SPP[tag], args.seed)
