@@ -963,7 +963,8 @@ __device__ __forceinline__ f3 csLightSum(f3 sum, const CsTerms &t, uint32_t nb, 
 #ifndef QA_CS_WAVES_TEX
 #define QA_CS_WAVES_TEX 4
 #endif
-__host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) { return items + 8u * slots + QA_CS_RES_WORDS + 64u + QA_LANE_SLOTS * 64u; }
+#define QA_CS_LANE_SLOTS 12   /* per-lane LDS floats: running mean and variance of the pixel (6), the path's throughput and radiance (6) */
+__host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) { return items + 8u * slots + QA_CS_RES_WORDS + 64u + QA_CS_LANE_SLOTS * 64u; }
 
 // What a path keeps between its segments besides its ray, throughput and radiance, in one word: bounceCount the next hit is
 // shaded with | hInfo.c.hasDiffuseHit of the next hit | camera ray | 1 + the material the ray was spawned from (its absorption
@@ -1002,6 +1003,13 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     L.slots = sc.csSlots;
   }
   float *acc = reinterpret_cast<float *>(L.items + sc.csItems) + lane;   // + i * 64
+  // The path's throughput and the sample's radiance live in LDS too (columns 6 - 11): they are touched at a handful of points of an
+  // iteration and would otherwise be six more registers alive through every sweep and every round (- 19 / - 34 spilled registers in the
+  // untextured / textured kernels); the pool gives up 256 items and 16 ray slots for them.
+#define QA_PT() F3(acc[6 * 64], acc[7 * 64], acc[8 * 64])
+#define QA_PL() F3(acc[9 * 64], acc[10 * 64], acc[11 * 64])
+#define QA_SET_PT(v) { const f3 t_ = (v); acc[6 * 64] = t_.x; acc[7 * 64] = t_.y; acc[8 * 64] = t_.z; }
+#define QA_SET_PL(v) { const f3 t_ = (v); acc[9 * 64] = t_.x; acc[10 * 64] = t_.y; acc[11 * 64] = t_.z; }
   const uint4 *mtlTable = reinterpret_cast<const uint4 *>(sc.mtl);
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
@@ -1031,7 +1039,6 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   Ray ray;
   ray.p = F3(0, 0, 0);
   ray.d = F3(0, 0, 1);
-  f3 pT = F3(0, 0, 0), pL = F3(0, 0, 0);
   uint32_t pst = QA_PST_PRIMARY;
   bool alive = true, needPixel = true, needSample = false;
   uint32_t nrec = 0;       // AREA: hits logged for the current path
@@ -1089,8 +1096,8 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       }
       ray.p = campos;
       ray.d = normalize(cpt - campos);
-      pT = F3(1, 1, 1);
-      pL = F3(0, 0, 0);
+      QA_SET_PT(F3(1, 1, 1))
+      QA_SET_PL(F3(0, 0, 0))
       pst = QA_PST_PRIMARY | (uint32_t) (rp.max_bounce & 0xFF);
       needSample = false;
     }
@@ -1125,14 +1132,14 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           } else
             c = sampleEnvironment(tt, c, sc.envTexmap, ray.d);
         }
-        pL = pL + pT * c;
+        QA_SET_PL(QA_PL() + QA_PT() * c)
         done = true;
       } else {
         const int absorbMtl = QA_PST_ABSORB(pst);
         if (!primary && !h.front && absorbMtl >= 0) {
           const uint4 ab = mtlTable[6 * (size_t) absorbMtl + 5];
           const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
-          pT = pT * att;
+          QA_SET_PT(QA_PT() * att)
         }
         const qa_instance &in = sc.inst[h.node];
         bool white = false;
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           } else mi = ms.first;
         }
         if (mi < 0) {
-          if (white) pL = pL + pT;
+          if (white) QA_SET_PL(QA_PL() + QA_PT())
           done = true;
         } else {
           V = -ray.d;
@@ -1153,7 +1160,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           // (shadeSurface inline: as a function of its own - tried for the untextured variants - its results come back through
           // memory or a block of registers that the caller spills: C4 3 790 vs 4 510, C5 1 590 vs 1 690 Msamples/s at 16 spp)
           sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, QA_PST_BOUNCE(pst), (pst & QA_PST_FROM_DIFFUSE) != 0, rng);
-          pL = pL + pT * sf.emission;
+          QA_SET_PL(QA_PL() + QA_PT() * sf.emission)
           lit = true;
         }
       }
@@ -1171,6 +1178,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       if (lit && nrec < QA_MAX_PATH) {
         const size_t stride = (size_t) gridDim.x * QA_BLOCK;
         float *rec = sc.areaScratch + (size_t) blockIdx.x * QA_BLOCK + threadIdx.x + (size_t) nrec * QA_REC_FLOATS * stride;
+        const f3 pT = QA_PT();
         const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, pT.x, pT.y, pT.z, sf.kd.x, sf.kd.y, sf.kd.z, sf.ks.x, sf.ks.y, sf.ks.z, sf.gloss};
 #pragma unroll
         for (int f = 0; f < QA_REC_FLOATS; ++f) rec[(size_t) f * stride] = v[f];
@@ -1192,12 +1200,12 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       }
     }
     if (lit) {
-      litT = pT;
+      litT = QA_PT();
       ray.p = p;
       if (sf.spawn) {
         // ComputeSecondaryRay (:226-254): DiffRay(pos, dir).Normalize()
         ray.d = normalize(sf.nextDir);
-        pT = pT * sf.bxdf;
+        QA_SET_PT(litT * sf.bxdf)
         pst = (uint32_t) ((QA_PST_BOUNCE(pst) - 1) & 0xFF) | (sf.nextFromDiffuse ? QA_PST_FROM_DIFFUSE : 0u) | ((uint32_t) (mi + 1) << 16);
       } else {
         done = true;
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
             dl = csLightSum(dl, terms, nb, occl);
           }
         }
-        if (lit) pL = pL + litT * dl;
+        if (lit) QA_SET_PL(QA_PL() + litT * dl)
         QA_TACC(cnt.sl[5], tL)
       }
     }
@@ -1323,7 +1331,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
             const f3 brdf = F3(v[12], v[13], v[14]) + F3(v[15], v[16], v[17]) * qpowf(cosNH, v[18]);
             sum = sum + (intensity * cosNL) * brdf;
           }
-          if (on) pL = pL + F3(v[9], v[10], v[11]) * sum;
+          if (on) QA_SET_PL(QA_PL() + F3(v[9], v[10], v[11]) * sum)
         }
         QA_TACC(cnt.sl[5], tL)
         done = awaiting;
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[64], acc[2 * 64]);
       f3 cstd = F3(acc[3 * 64], acc[4 * 64], acc[5 * 64]);
-      const f3 dc = (pL - mean) / inv;
+      const f3 dc = (QA_PL() - mean) / inv;
       mean = mean + dc;
       if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
       acc[0] = mean.x; acc[64] = mean.y; acc[2 * 64] = mean.z;
