@@ -820,8 +820,8 @@ static int PrepareScene(qa_ctx *c)
   ds.csInst = c->csInstDev;
   ds.csCull = c->csCullDev;
   ds.csCullS1 = c->csCullS1; ds.csCullS2 = c->csCullS2; ds.csCullK3 = c->csCullK3; ds.csCullK4 = c->csCullK4;
-  ds.csItems = DevEnv("QA_CS_ITEMS") ? (uint32_t) atoi(DevEnv("QA_CS_ITEMS")) : 640u;
-  ds.csSlots = DevEnv("QA_CS_SLOTS") ? (uint32_t) atoi(DevEnv("QA_CS_SLOTS")) : 96u;
+  ds.csItems = DevEnv("QA_CS_ITEMS") ? (uint32_t) atoi(DevEnv("QA_CS_ITEMS")) : 576u;
+  ds.csSlots = DevEnv("QA_CS_SLOTS") ? (uint32_t) atoi(DevEnv("QA_CS_SLOTS")) : 80u;
   if (ds.csSlots < 64u) ds.csSlots = 64u;     // an instance enters up to 64 rays at once
   if (ds.csSlots > 256u) ds.csSlots = 256u;   // 8 bits of an item
   if (ds.csItems < 128u) ds.csItems = 128u;

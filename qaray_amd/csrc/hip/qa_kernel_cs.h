@@ -493,7 +493,7 @@ __device__ __forceinline__ RayDiff csRayDiff(const DScene &sc, const Ray &world,
 }
 
 template <bool TEX, bool CULL>
-__device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L, bool act, const Ray &world, bool primary, uint32_t pxy, int sidx, Hit &h, TexHit &th,
+__device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L, bool act, const Ray &world, bool primary, const float *cols, Hit &h, TexHit &th,
                                                DCounters &cnt)
 {
   if (!__any(act)) return false;
@@ -650,7 +650,7 @@ __device__ __forceinline__ bool csTraceClosest(const DScene &sc, const CsLds &L,
     if (!__any(pending)) continue;
     RayDiff wd;
     wd.dx = wd.dy = world.d;
-    if (TEX) wd = csRayDiff(sc, world, primary, pxy, sidx);
+    if (TEX) wd = csRayDiff(sc, world, primary, __float_as_uint(cols[12 * 64]), __float_as_int(cols[14 * 64]));   // (pixel and sample index: the wave's LDS columns)
     for (int k = 1; k < sc.num_inst; ++k) {
       const bool mine = pending && winK == k;
       if (!__any(mine)) continue;
@@ -963,7 +963,7 @@ __device__ __forceinline__ f3 csLightSum(f3 sum, const CsTerms &t, uint32_t nb, 
 #ifndef QA_CS_WAVES_TEX
 #define QA_CS_WAVES_TEX 4
 #endif
-#define QA_CS_LANE_SLOTS 12   /* per-lane LDS floats: running mean and variance of the pixel (6), the path's throughput and radiance (6) */
+#define QA_CS_LANE_SLOTS 15   /* per-lane LDS words: running mean and variance of the pixel (6), the path's throughput and radiance (6), pixel | output index | sample index */
 __host__ __device__ inline uint32_t CsLdsWords(uint32_t items, uint32_t slots) { return items + 8u * slots + QA_CS_RES_WORDS + 64u + QA_CS_LANE_SLOTS * 64u; }
 
 // What a path keeps between its segments besides its ray, throughput and radiance, in one word: bounceCount the next hit is
@@ -1010,6 +1010,13 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
 #define QA_PL() F3(acc[9 * 64], acc[10 * 64], acc[11 * 64])
 #define QA_SET_PT(v) { const f3 t_ = (v); acc[6 * 64] = t_.x; acc[7 * 64] = t_.y; acc[8 * 64] = t_.z; }
 #define QA_SET_PL(v) { const f3 t_ = (v); acc[9 * 64] = t_.x; acc[10 * 64] = t_.y; acc[11 * 64] = t_.z; }
+  // ... and so do the pixel (x | y << 16), its output index and the sample index (columns 12 - 14): read at the sample's start and end
+#define QA_PXY() __float_as_uint(acc[12 * 64])
+#define QA_Q() __float_as_uint(acc[13 * 64])
+#define QA_SIDX() __float_as_int(acc[14 * 64])
+  // (lanes that hold no pixel - padding lanes of ragged tiles, lanes before their first tile - still run the wave's code: their sample
+  // index is an index into the Halton table in csRayDiff / csTexPos, so every column starts from zero)
+  for (int i = 0; i < QA_CS_LANE_SLOTS; ++i) acc[i * 64] = 0.f;
   const uint4 *mtlTable = reinterpret_cast<const uint4 *>(sc.mtl);
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
@@ -1032,10 +1039,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   tt.filter = sc.texFilter;
 
   // per-lane state: pixel (x | y << 16, output index, RNG stream, sample index) and path (ray, throughput, radiance, state word)
-  uint32_t pxy = 0;
-  unsigned q = 0;
   uint32_t rng = 1;
-  int sidx = 0;
   Ray ray;
   ray.p = F3(0, 0, 0);
   ray.d = F3(0, 0, 1);
@@ -1066,10 +1070,10 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
           const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
           if (tx < (unsigned) rw && ty < (unsigned) rh) {
             const uint32_t px = (uint32_t) rp.x0 + tx, py = (uint32_t) rp.y0 + ty;
-            pxy = px | (py << 16);
-            q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
+            acc[12 * 64] = __uint_as_float(px | (py << 16));
+            acc[13 * 64] = __uint_as_float((otr * 8 + (in / 8)) * (unsigned) rw + tx);
             rng = qa_pixel_seed(rp.seed, py * (uint32_t) sc.cam.width + px);
-            sidx = 0;
+            acc[14 * 64] = __int_as_float(0);
             for (int i = 0; i < 6; ++i) acc[i * 64] = 0.f;
             needSample = true;
             needPixel = false;
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     const bool starting = alive && needSample && goSample;
     cnt.samples += (unsigned long long) __popcll(__ballot(starting));   // (wave-uniform tallies: no registers per lane)
     if (starting) {
-      const f3 texpos = csTexPos(sc, pxy, sidx);
+      const f3 texpos = csTexPos(sc, QA_PXY(), QA_SIDX());
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
       const f3 cpt = (A + U * texpos.x) + V * texpos.y;
       f3 campos = ld3(sc.cam.pos);
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     Hit h;
     TexHit th;
     QA_T(tC)
-    const bool found = csTraceClosest<TEX, CULL>(sc, L, act, ray, (pst & QA_PST_PRIMARY) != 0, pxy, sidx, h, th, cnt);
+    const bool found = csTraceClosest<TEX, CULL>(sc, L, act, ray, (pst & QA_PST_PRIMARY) != 0, acc, h, th, cnt);
     QA_TACC(cnt.sl[2], tC)
     QA_T(tD)
 
@@ -1122,12 +1126,12 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     sf.spawn = sf.nextFromDiffuse = sf.selDiffuse = false;
     if (act) {
       const bool primary = (pst & QA_PST_PRIMARY) != 0;
-      if (primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
+      if (primary && QA_SIDX() == 0) rp.depth[QA_Q()] = found ? h.z : QA_BIGFLOAT;
       if (!found) {
         f3 c = primary ? ld3(sc.background) : ld3(sc.environment);
         if (TEX) {
           if (primary) {
-            const f3 texpos = csTexPos(sc, pxy, sidx);
+            const f3 texpos = csTexPos(sc, QA_PXY(), QA_SIDX());
             c = texColorSample(tt, c, sc.bgTexmap, F3(texpos.x / (float) sc.cam.width, texpos.y / (float) sc.cam.height, 0.f));
           } else
             c = sampleEnvironment(tt, c, sc.envTexmap, ray.d);
@@ -1272,7 +1276,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
               for (;;) {
                 const bool more = on && ns < spp;
                 if (!__any(more)) break;
-                CsRays4 q;
+                CsRays4 rq;
                 f3 dir0 = F3(0, 0, 1), dir1 = dir0, dir2 = dir0, dir3 = dir0;
                 if (more) {
                   dir0 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
@@ -1280,11 +1284,11 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
                   dir2 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
                   dir3 = (ld3(l.position) + uniformBall(rng, l.size)) - hp;
                 }
-                q.d0 = normalize(dir0); q.t0 = length(dir0);
-                q.d1 = normalize(dir1); q.t1 = length(dir1);
-                q.d2 = normalize(dir2); q.t2 = length(dir2);
-                q.d3 = normalize(dir3); q.t3 = length(dir3);
-                const uint32_t occl = csShadowRays<CULL>(sc, L, more ? 15u : 0u, 4u, hp, q, cnt);
+                rq.d0 = normalize(dir0); rq.t0 = length(dir0);
+                rq.d1 = normalize(dir1); rq.t1 = length(dir1);
+                rq.d2 = normalize(dir2); rq.t2 = length(dir2);
+                rq.d3 = normalize(dir3); rq.t3 = length(dir3);
+                const uint32_t occl = csShadowRays<CULL>(sc, L, more ? 15u : 0u, 4u, hp, rq, cnt);
                 if (more) {
 #define QA_CS_FOLD(S, DIR)                                                                                                   \
                   {                                                                                                            \
@@ -1303,19 +1307,19 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
               I = ld3(l.intensity) * inshadow;
               if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, hp);
             } else {
-              CsRays4 q;
-              q.d1 = q.d2 = q.d3 = F3(0, 0, 1);
-              q.t1 = q.t2 = q.t3 = 0.f;
+              CsRays4 rq;
+              rq.d1 = rq.d2 = rq.d3 = F3(0, 0, 1);
+              rq.t1 = rq.t2 = rq.t3 = 0.f;
               f3 dir = F3(0, 0, 1);
               if (l.type == QA_LIGHT_DIRECT) {
-                q.d0 = normalize(-ld3(l.direction));
-                q.t0 = QA_BIGFLOAT;
+                rq.d0 = normalize(-ld3(l.direction));
+                rq.t0 = QA_BIGFLOAT;
               } else {
                 dir = ld3(l.position) - hp;
-                q.d0 = normalize(dir);
-                q.t0 = length(dir);
+                rq.d0 = normalize(dir);
+                rq.t0 = length(dir);
               }
-              const uint32_t occl = csShadowRays<CULL>(sc, L, on ? 1u : 0u, 1u, hp, q, cnt);
+              const uint32_t occl = csShadowRays<CULL>(sc, L, on ? 1u : 0u, 1u, hp, rq, cnt);
               const float shadowed = (occl & 1u) ? 0.0f : 1.0f;
               if (l.type == QA_LIGHT_DIRECT) I = ld3(l.intensity) * shadowed;
               else {
@@ -1342,6 +1346,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     // ---- E. sample finished (qa_integrate, section E; scene.cpp:92-121)
     bool pixelDone = false;
     if (alive && done) {
+      int sidx = QA_SIDX();
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[64], acc[2 * 64]);
       f3 cstd = F3(acc[3 * 64], acc[4 * 64], acc[5 * 64]);
@@ -1351,10 +1356,12 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       acc[0] = mean.x; acc[64] = mean.y; acc[2 * 64] = mean.z;
       acc[3 * 64] = cstd.x; acc[4 * 64] = cstd.y; acc[5 * 64] = cstd.z;
       ++sidx;
+      acc[14 * 64] = __int_as_float(sidx);
       const bool more = sidx < rp.spp_min || (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
         needSample = true;
       } else {
+        const uint32_t q = QA_Q();
         rp.rgb[3 * q + 0] = mean.x;
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
