@@ -156,6 +156,9 @@ int qa_set_pipeline(qa_ctx *ctx, int mode);
  *                    node is visited as the reference does (same bits either way: A/B tests)
  *   "cs_force_exact" tests: bit 0 / bit 1 send every closest-hit / shadow query of the cooperative kernel to its exact sequential
  *                    walks (the path a tie, a failed order check or a full pool takes); same bits, much slower
+ *   "walk_zero_terms" tests: 1 = the shadow ray of a light whose term is zero in every component whatever the ray finds (the surface
+ *                    faces away from the light) is walked all the same, as the reference does; 0 (default) = counted, not walked
+ *                    (same bits, same counters)
  *   "cs_pool_limit"  n > 0: upper bound for the pool of the cooperative walks (tests: forces the overflow path); 0 = none
  *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together
  *   "tile_order"     1 (default) / 0: tiles handed out centre-first

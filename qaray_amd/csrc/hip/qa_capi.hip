@@ -801,7 +801,9 @@ static int PrepareScene(qa_ctx *c)
   const size_t stackBytes = ((size_t) c->stackDepth + QA_LANE_SLOTS) * QA_BLOCK * sizeof(uint32_t);
   const size_t imageBytes = image.size() * sizeof(uint4);
   if (stackBytes > kMaxLdsPerBlock) return Fail(QA_EUNSUPPORTED, "BVH too deep for the LDS traversal stack");
-  c->resident = (imageBytes > 0 && imageBytes + stackBytes <= kResidentLdsBudget &&
+  // workgroups of a resident scene also keep the cold path state in LDS columns (QA_LANE_SLOTS_RES)
+  const size_t stackBytesRes = ((size_t) c->stackDepth + QA_LANE_SLOTS_RES) * QA_BLOCK * sizeof(uint32_t);
+  c->resident = (imageBytes > 0 && imageBytes + stackBytesRes <= kResidentLdsBudget &&
                  h->num_instances <= QA_KARG_INST && h->num_meshes <= QA_KARG_MESH);
   if (c->resident) {
     const uint4 *dimg = nullptr;
@@ -812,7 +814,7 @@ static int PrepareScene(qa_ctx *c)
     for (uint32_t k = 0; k < h->num_instances; ++k) ds.instv[k] = inst[k];
     for (uint32_t k = 0; k < h->num_meshes; ++k) ds.meshv[k] = dmeshes[k];
   }
-  c->ldsBytes = stackBytes + (c->resident ? imageBytes : 0);
+  c->ldsBytes = c->resident ? stackBytesRes + imageBytes : stackBytes;
   // qa_integrate_cs: per wave [ray slots | results | flags | pool items | accumulators]; four workgroups per CU (160 KB LDS)
   ds.csNodes = c->csNodesDev;
   ds.csTris = c->csTrisDev;
@@ -944,6 +946,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
   ds.csCullOn = (c->optCsCull && c->csCullOk) ? 1u : 0u;
   ds.csForceExact = c->optCsForceExact;
+  ds.walkZeroTerms = c->optWalkZeroTerms;
   ds.csPoolLimit = DevEnv("QA_CS_POOL") ? (uint32_t) std::max(64, atoi(DevEnv("QA_CS_POOL"))) : c->optCsPool;
   const size_t ldsBytes = pmOn ? c->ldsBytesPm : (cs ? c->ldsBytesCs : c->ldsBytes);
   const KernelFn kernel = pmOn ? ((flags & QA_RENDER_STATS) ? c->kernelPmStats : c->kernelPm)
@@ -1343,6 +1346,7 @@ int qa_set_option(qa_ctx *c, const char *name, long long value)
     if (c->haveScene) return SelectKernel(c);
   } else if (n == "cs_cull") c->optCsCull = value != 0;
   else if (n == "cs_force_exact") c->optCsForceExact = (uint32_t) (value & 3);
+  else if (n == "walk_zero_terms") c->optWalkZeroTerms = value ? 1u : 0u;
   else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
   else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "tile_order") c->tileOrder = value != 0;

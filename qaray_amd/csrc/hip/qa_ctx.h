@@ -143,6 +143,7 @@ struct qa_ctx {
   // qa_set_option
   bool optCoop = true;          // "coop": cooperative mesh walks (qa_kernel_cs.h) where the scene allows them
   bool optCsCull = true;        // "cs_cull": instance culling in the cooperative kernel's sweeps (0: every instance is visited; A/B tests)
+  uint32_t optWalkZeroTerms = 0; // "walk_zero_terms": tests - also walk the shadow rays of lights whose term is zero whatever they find
   uint32_t optCsForceExact = 0; // "cs_force_exact": tests of the exact walks (bit 0 closest-hit, bit 1 shadow queries)
   uint32_t optCsPool = 0;       // "cs_pool_limit": upper bound for the walks' pool capacity (tests force the overflow path)
   bool optVerbose = false;      // "verbose": tree / launch-shape report on stderr at upload

@@ -1023,6 +1023,39 @@ __device__ __forceinline__ f3 directLight(const SceneMem<RES> mem, const DScene 
   for (int li = 0; li < sc.num_lights; ++li) {
     const qa_light l = ldTable(sc.light + li);
     if (l.type == QA_LIGHT_AMBIENT) continue;
+    if (!STATS && !(l.type != QA_LIGHT_DIRECT && l.size > 0.01f)) {
+      // Not an area light, nothing to count: the term first, as if unshadowed (a shadow factor of 1.0f multiplies exactly), the shadow
+      // ray only when that term is not zero in every component - a surface facing away from the light (cosNL = max(0, N.L) = 0) adds
+      // the same zero whether it is occluded or not; an occluded light's term is the unshadowed one times 0.0f (the reference's term
+      // with the factor 0.0f: a zero of some sign - or a NaN exactly when the unshadowed term is not finite; a sum that started
+      // from +0 does not see the sign of a zero).  qa_kernel_cs.h's csLightTerms / csLightSum, one lane at a time.
+      f3 I;
+      Ray r;
+      r.p = p;
+      float tmax = QA_BIGFLOAT;
+      if (l.type == QA_LIGHT_DIRECT) {
+        I = ld3(l.intensity) * 1.0f;
+        r.d = normalize(-ld3(l.direction));
+      } else {
+        const f3 dir = ld3(l.position) - p;
+        r.d = normalize(dir);
+        tmax = length(dir);
+        I = (ld3(l.intensity) * 1.0f) * inverseSquareFalloff(dir);
+        if (l.type == QA_LIGHT_SPOT) I = I * spotAttenuation(l, p);
+      }
+      const f3 intensity = I * normCoefDI;
+      const f3 Ld = normalize(-lightDirection(l, p));
+      const f3 H = normalize(V + Ld);
+      const float cosNL = qmax(0.f, dot(N, Ld));
+      const float cosNH = qmax(0.f, dot(N, H));
+      const f3 brdf = kd + ks * qpowf(cosNH, gloss);
+      const f3 u = (intensity * cosNL) * brdf;
+      const bool walk = sc.walkZeroTerms || !(u.x == 0.f && u.y == 0.f && u.z == 0.f);
+      if (!walk) QA_TALLY(cnt.casts_shadow);   // (the reference casts it: counted, not walked)
+      const bool occluded = walk && shadow<RES, STATS>(mem, sc, r, tmax, stack, cnt) == 0.0f;
+      sum = sum + (occluded ? u * 0.0f : u);
+      continue;
+    }
     const f3 intensity = illuminate<RES, STATS>(mem, sc, l, p, stack, cnt, rng) * normCoefDI;
     const f3 Ld = normalize(-lightDirection(l, p));
     const f3 H = normalize(V + Ld);
@@ -1356,6 +1389,17 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   // are touched once per sample, registers are better spent on the traversal
   float *acc = reinterpret_cast<float *>(stack + (size_t) sc.stackDepth * QA_BLOCK - threadIdx.x) + threadIdx.x;
   const uint4 *mtlTable = RES ? s_dyn + sc.resMaterials : reinterpret_cast<const uint4 *>(sc.mtl);
+  // LDS-resident scenes have shallow stacks: their workgroups also keep the path's throughput and radiance, the pixel, its output
+  // index and the sample index in LDS columns (QA_LANE_SLOTS_RES) - state touched at a handful of points of an iteration
+  constexpr bool LCOLS = RES && !PHOTON;   // (a photon gather's stack is deep: those variants keep the registers)
+  if (LCOLS)
+    for (int i = QA_LANE_SLOTS; i < QA_LANE_SLOTS_RES; ++i) acc[i * QA_BLOCK] = 0.f;
+#define QA_GET_T() (LCOLS ? F3(acc[6 * QA_BLOCK], acc[7 * QA_BLOCK], acc[8 * QA_BLOCK]) : path.T)
+#define QA_GET_L() (LCOLS ? F3(acc[9 * QA_BLOCK], acc[10 * QA_BLOCK], acc[11 * QA_BLOCK]) : path.L)
+#define QA_PUT_T(...) { const f3 v_ = (__VA_ARGS__); if (LCOLS) { acc[6 * QA_BLOCK] = v_.x; acc[7 * QA_BLOCK] = v_.y; acc[8 * QA_BLOCK] = v_.z; } else path.T = v_; }
+#define QA_PUT_L(...) { const f3 v_ = (__VA_ARGS__); if (LCOLS) { acc[9 * QA_BLOCK] = v_.x; acc[10 * QA_BLOCK] = v_.y; acc[11 * QA_BLOCK] = v_.z; } else path.L = v_; }
+#define QA_GET_Q() (LCOLS ? __float_as_uint(acc[13 * QA_BLOCK]) : q)
+#define QA_GET_SIDX() (LCOLS ? __float_as_int(acc[14 * QA_BLOCK]) : sidx)
 
   // work items walk 8x8 pixel tiles (a wave starts on a compact screen patch); ragged right /
   // bottom tiles contain padding slots that are simply skipped.
@@ -1434,6 +1478,11 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
             rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
             sidx = 0;
+            if (LCOLS) {
+              acc[12 * QA_BLOCK] = __uint_as_float((unsigned) px | ((unsigned) py << 16));
+              acc[13 * QA_BLOCK] = __uint_as_float(q);
+              acc[14 * QA_BLOCK] = __int_as_float(0);
+            }
             for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;
             needSample = true;
             needPixel = false;
@@ -1449,8 +1498,14 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
     // camera rays of a tile are traced together instead of next to incoherent secondary rays
     const bool goSample = !rp.sync_samples || (__ballot(needSample) == __ballot(alive && !needPixel));
     if (alive && needSample && goSample) {
-      const float hx = sc.halton[2 * sidx], hy = sc.halton[2 * sidx + 1];
-      texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
+      const int si = QA_GET_SIDX();
+      const float hx = sc.halton[2 * si], hy = sc.halton[2 * si + 1];
+      if (LCOLS) {
+        const unsigned pxy = __float_as_uint(acc[12 * QA_BLOCK]);
+        texpos = F3(hx, hy, 0.f) + F3((float) (int) (pxy & 0xFFFFu), (float) (int) (pxy >> 16), 0.f);
+      } else {
+        texpos = F3(hx, hy, 0.f) + F3((float) px, (float) py, 0.f);
+      }
       const f3 A = ld3(sc.cam.screenA), U = ld3(sc.cam.screenU), V = ld3(sc.cam.screenV);
       const f3 cpt = (A + U * texpos.x) + V * texpos.y;
       f3 campos = ld3(sc.cam.pos);
@@ -1470,8 +1525,8 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         pathDiff.dx = normalize(xpt - campos);
         pathDiff.dy = normalize(ypt - campos);
       }
-      path.T = F3(1, 1, 1);
-      path.L = F3(0, 0, 0);
+      QA_PUT_T(F3(1, 1, 1))
+      QA_PUT_L(F3(0, 0, 0))
       path.absorbMtl = -1;
       path.bounce = rp.max_bounce;
       path.fromDiffuse = false;
@@ -1499,7 +1554,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       QA_T(tC)
       const bool found = traceClosest<RES, TEX, STATS>(mem, sc, path.ray, pathDiff, h, th, stack, cnt);
       QA_TACC(cnt.sl[2], tC)
-      if (path.primary && sidx == 0) rp.depth[q] = found ? h.z : QA_BIGFLOAT;
+      if (path.primary && QA_GET_SIDX() == 0) rp.depth[QA_GET_Q()] = found ? h.z : QA_BIGFLOAT;
 
       QA_T(tM)
       if (!found) {
@@ -1512,7 +1567,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           else
             c = sampleEnvironment(tt, c, sc.envTexmap, path.ray.d);
         }
-        path.L = path.L + path.T * c;
+        QA_PUT_L(QA_GET_L() + QA_GET_T() * c)
         done = true;
         QA_TACC(cnt.sl[10], tM)
       } else {
@@ -1522,7 +1577,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
         if (!path.primary && !h.front && path.absorbMtl >= 0) {
           const uint4 ab = mtlTable[6 * (size_t) path.absorbMtl + 5];
           const f3 att = F3(qexpf(-asF(ab.x) * h.z), qexpf(-asF(ab.y) * h.z), qexpf(-asF(ab.z) * h.z));
-          path.T = path.T * att;
+          QA_PUT_T(QA_GET_T() * att)
         }
         const qa_instance &in = instAt<RES>(sc, h.node);
         int mi = -1;
@@ -1535,7 +1590,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           } else mi = ms.first;
         }
         if (mi < 0) {
-          if (white) path.L = path.L + path.T;
+          if (white) QA_PUT_L(QA_GET_L() + QA_GET_T())
           done = true;
         } else {
           const f3 V = -path.ray.d;
@@ -1545,7 +1600,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           QA_T(tD)
           const Surface sf = shadeSurface<TEX>(mtlTable, sc, tt, mi, N, V, h.front, th, path.bounce, path.fromDiffuse, rng);
           QA_TACC(cnt.sl[4], tD)
-          path.L = path.L + path.T * sf.emission;
+          QA_PUT_L(QA_GET_L() + QA_GET_T() * sf.emission)
           const f3 sampleDiffuse = sf.kd, sampleSpecular = sf.ks;
           const float glossSpec = sf.gloss;
           const bool spawn = sf.spawn;
@@ -1557,18 +1612,19 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             // a heap share a cache line that way: 10 - 12 % faster than slot-major columns)
             uint2 *heap = rp.heap + ((size_t) blockIdx.x * QA_BLOCK + threadIdx.x) * (QA_PHOTON_GATHER + 1);
             if (path.fromDiffuse)
-              path.L = path.L + path.T * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
-            path.L = path.L + path.T * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap);
+              QA_PUT_L(QA_GET_L() + QA_GET_T() * photonGather(rp.pm[0], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap))
+            QA_PUT_L(QA_GET_L() + QA_GET_T() * photonGather(rp.pm[1], p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, heap))
           }
 
           // direct lighting (:481-498)
           if (LIGHTS && !AREA) {
             QA_T(tL)
-            path.L = path.L + path.T * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng);
+            QA_PUT_L(QA_GET_L() + QA_GET_T() * directLight<RES, STATS>(mem, sc, p, N, V, sampleDiffuse, sampleSpecular, glossSpec, stack, cnt, rng))
             QA_TACC(cnt.sl[5], tL)
           }
           if (AREA && nrec < QA_MAX_PATH) {
-            const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, path.T.x, path.T.y, path.T.z,
+            const f3 pT = QA_GET_T();
+            const float v[QA_REC_FLOATS] = {p.x, p.y, p.z, N.x, N.y, N.z, V.x, V.y, V.z, pT.x, pT.y, pT.z,
                                             sampleDiffuse.x, sampleDiffuse.y, sampleDiffuse.z,
                                             sampleSpecular.x, sampleSpecular.y, sampleSpecular.z, glossSpec};
             for (int f = 0; f < QA_REC_FLOATS; ++f) rec[(size_t) (nrec * QA_REC_FLOATS + f) * recStride] = v[f];
@@ -1581,7 +1637,7 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             path.ray.p = p;
             path.ray.d = normalize(nextDir);
             if (TEX) pathDiff.dx = pathDiff.dy = path.ray.d;  // DiffRay(pos, dir): x = y = c (ray.h:57-63)
-            path.T = path.T * bxdf;
+            QA_PUT_T(QA_GET_T() * bxdf)
             path.absorbMtl = mi;
             path.bounce -= 1;
             path.fromDiffuse = nextFromDiffuse;
@@ -1606,28 +1662,32 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
           for (int f = 0; f < QA_REC_FLOATS; ++f) v[f] = rec[(size_t) (lvl * QA_REC_FLOATS + f) * recStride];
           const f3 d = directLight<RES, STATS>(mem, sc, F3(v[0], v[1], v[2]), F3(v[3], v[4], v[5]), F3(v[6], v[7], v[8]),
                                                F3(v[12], v[13], v[14]), F3(v[15], v[16], v[17]), v[18], stack, cnt, rng);
-          path.L = path.L + F3(v[9], v[10], v[11]) * d;
+          QA_PUT_L(QA_GET_L() + F3(v[9], v[10], v[11]) * d)
         }
         nrec = 0;
       }
+      if (LCOLS) sidx = QA_GET_SIDX();
+      const unsigned qo = QA_GET_Q();
+      const f3 pL = QA_GET_L();
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
       f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
-      const f3 dc = (path.L - mean) / inv;
+      const f3 dc = (pL - mean) / inv;
       mean = mean + dc;
       if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
       acc[0] = mean.x; acc[QA_BLOCK] = mean.y; acc[2 * QA_BLOCK] = mean.z;
       acc[3 * QA_BLOCK] = cstd.x; acc[4 * QA_BLOCK] = cstd.y; acc[5 * QA_BLOCK] = cstd.z;
       ++sidx;
+      if (LCOLS) acc[14 * QA_BLOCK] = __int_as_float(sidx);
       const bool more = sidx < rp.spp_min ||
                         (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
         needSample = true;
       } else {
-        rp.rgb[3 * q + 0] = mean.x;
-        rp.rgb[3 * q + 1] = mean.y;
-        rp.rgb[3 * q + 2] = mean.z;
-        rp.ns[q] = (uint32_t) sidx;
+        rp.rgb[3 * qo + 0] = mean.x;
+        rp.rgb[3 * qo + 1] = mean.y;
+        rp.rgb[3 * qo + 2] = mean.z;
+        rp.ns[qo] = (uint32_t) sidx;
         QA_TALLY(cnt.pixels);
         needPixel = true;
       }

@@ -752,7 +752,6 @@ template <bool CULL>
 __device__ __forceinline__ void csShadowSweep(const DScene &sc, const CsLds &L, bool lit, const Ray &w, float tmax, uint32_t jj, uint32_t nb, uint32_t &occl,
                                               uint32_t &redo, uint32_t &n, uint32_t &nSlots, DCounters &cnt)
 {
-  cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
   const Ray r0 = rootRay<false>(sc, w);
   GroupRay grp;
   grp.node = -1;
@@ -803,8 +802,11 @@ __device__ __forceinline__ void csShadowSweep(const DScene &sc, const CsLds &L, 
 // onwards; on return li is where the following batch starts and nb the lights taken), for the lanes with `lit`: bit jj of the
 // result = light jj of the batch occluded.  The reference stops at the first node that occludes; which one does not matter.
 // The pool runs once, after the sweeps of all the batch's lights (and, rarely, in between when it cannot take an instance's rays).
+// `need`: bit jj = the lane's term of light jj is not zero in every component.  A light whose unshadowed term is (+-0, +-0, +-0) - the
+// surface faces away from it: cosNL = max(0, N.L) = 0 - adds the same zero whether it is occluded or not (csLightSum), so its shadow
+// ray is counted (the reference casts it) and not walked.
 template <bool CULL>
-__device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds &L, bool lit, f3 p, int &li, uint32_t &nb, DCounters &cnt)
+__device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds &L, bool lit, uint32_t need, f3 p, int &li, uint32_t &nb, DCounters &cnt)
 {
   const unsigned lane = __lane_id();
   uint32_t occl = 0, redo = 0;
@@ -820,7 +822,8 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
     Ray w;
     float tmax;
     csShadowRay(l, p, w, tmax);
-    csShadowSweep<CULL>(sc, L, lit, w, tmax, jj, nb, occl, redo, n, nSlots, cnt);
+    cnt.casts_shadow += (unsigned long long) __popcll(__ballot(lit));
+    csShadowSweep<CULL>(sc, L, lit && ((need >> jj) & 1u), w, tmax, jj, nb, occl, redo, n, nSlots, cnt);
   }
   if (n != 0) {
     csRun<false>(sc, L, n, QA_FILL(cnt));
@@ -828,7 +831,7 @@ __device__ __forceinline__ uint32_t csShadowBatch(const DScene &sc, const CsLds 
   }
   QA_TACC(cnt.sl[17], tSweep)
   // ---- the exact repeats
-  if (sc.csForceExact & 2u) { occl = 0; redo = lit ? (1u << nb) - 1u : 0u; }   // (option "cs_force_exact": tests of the exact walks)
+  if (sc.csForceExact & 2u) { occl = 0; redo = lit ? need & ((1u << nb) - 1u) : 0u; }   // (option "cs_force_exact": tests of the exact walks)
   redo &= ~occl;
 #ifdef QA_STAMPS
   if (lane == 0) cnt.sl[16] += (unsigned long long) __popcll(__ballot(lit && redo != 0));
@@ -865,6 +868,7 @@ __device__ __forceinline__ uint32_t csShadowRays(const DScene &sc, const CsLds &
     Ray w;                                                                                            \
     w.p = p;                                                                                          \
     w.d = D;                                                                                          \
+    cnt.casts_shadow += (unsigned long long) __popcll(__ballot(((mask >> S) & 1u) != 0));            \
     csShadowSweep<CULL>(sc, L, ((mask >> S) & 1u) != 0, w, T, S, S + 1u, occl, redo, n, nSlots, cnt); \
   }
   QA_CS_RAY(0u, q.d0, q.t0)
@@ -940,6 +944,11 @@ __device__ __forceinline__ CsTerms csLightTerms(const DScene &sc, bool lit, int 
     ++j;
   }
   return t;
+}
+__device__ __forceinline__ uint32_t csTermsNeed(const CsTerms &t)
+{
+  auto nz = [](f3 c) { return !(c.x == 0.f && c.y == 0.f && c.z == 0.f); };   // (a NaN term keeps its ray)
+  return (nz(t.c0) ? 1u : 0u) | (nz(t.c1) ? 2u : 0u) | (nz(t.c2) ? 4u : 0u) | (nz(t.c3) ? 8u : 0u);
 }
 __device__ __forceinline__ f3 csLightSum(f3 sum, const CsTerms &t, uint32_t nb, uint32_t occl)
 {
@@ -1221,7 +1230,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         QA_T(tL)
         int li = 0;
         uint32_t nb = 0;
-        uint32_t occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
+        uint32_t occl = csShadowBatch<CULL>(sc, L, lit, csTermsNeed(terms) | (sc.walkZeroTerms ? 15u : 0u), ray.p, li, nb, cnt);
         f3 dl = csLightSum(F3(0, 0, 0), terms, nb, occl);
         if (MANY) {
           // the further batches of a scene with many lights: surface back from the slab, terms, shadow queries, sum - in table order
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
 #pragma unroll
             for (int f = 0; f < 13; ++f) v[f] = lit ? sv[f * stride] : 0.f;
             terms = csLightTerms(sc, lit, li0, ray.p, F3(v[0], v[1], v[2]), F3(v[3], v[4], v[5]), F3(v[6], v[7], v[8]), F3(v[9], v[10], v[11]), v[12]);
-            occl = csShadowBatch<CULL>(sc, L, lit, ray.p, li, nb, cnt);
+            occl = csShadowBatch<CULL>(sc, L, lit, csTermsNeed(terms) | (sc.walkZeroTerms ? 15u : 0u), ray.p, li, nb, cnt);
             if (!nb) break;   // (only ambient lights were left)
             dl = csLightSum(dl, terms, nb, occl);
           }
@@ -1319,7 +1328,11 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
                 rq.d0 = normalize(dir);
                 rq.t0 = length(dir);
               }
-              const uint32_t occl = csShadowRays<CULL>(sc, L, on ? 1u : 0u, 1u, hp, rq, cnt);
+              // (a surface facing away from the light - cosNL = 0 - gets the same zero whether the light is occluded or not: its shadow
+              // ray is counted and not walked, csShadowBatch)
+              const bool walk = on && (sc.walkZeroTerms || qmax(0.f, dot(hN, normalize(-lightDirection(l, hp)))) != 0.f);
+              cnt.casts_shadow += (unsigned long long) __popcll(__ballot(on && !walk));
+              const uint32_t occl = csShadowRays<CULL>(sc, L, walk ? 1u : 0u, 1u, hp, rq, cnt);
               const float shadowed = (occl & 1u) ? 0.0f : 1.0f;
               if (l.type == QA_LIGHT_DIRECT) I = ld3(l.intensity) * shadowed;
               else {

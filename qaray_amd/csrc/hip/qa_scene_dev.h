@@ -153,6 +153,7 @@ struct alignas(32) CsCull {
 static_assert(sizeof(CsCull) == 32, "CsCull must be 8 dwords");
 
 #define QA_LANE_SLOTS 6   /* per-lane LDS floats behind the traversal stack: running mean and variance of the pixel */
+#define QA_LANE_SLOTS_RES 15   /* LDS-resident scenes: + throughput, radiance, pixel, output index, sample index */
 #define QA_KARG_INST 12   /* scene-graph nodes / meshes a resident scene may pass by value */
 #define QA_KARG_MESH 4
 
@@ -202,6 +203,7 @@ struct DScene {
   float csCullS1, csCullS2, csCullK3, csCullK4;
   uint32_t csCullOn;
   float *csSurf;               // scenes with more than QA_CS_LIGHT_BATCH shadow-casting lights: [13][grid lanes] surface columns (qa_kernel_cs.h), else nullptr
+  uint32_t walkZeroTerms;      // tests (option "walk_zero_terms"): shadow rays of lights whose unshadowed term is zero are walked too (same frame, slower)
   uint32_t csForceExact;       // tests (option "cs_force_exact"): bit 0 = every closest-hit query, bit 1 = every shadow query goes to the exact walks
   uint32_t csItems, csSlots;   // per-wave pool capacity (items) and ray slots of the LDS layout
   // resident scenes only: the tables themselves, in the kernel-argument segment

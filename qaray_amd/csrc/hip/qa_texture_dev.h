@@ -152,16 +152,63 @@ __device__ __forceinline__ f3 textureSample(const TexTables &tt, int ti, f3 uvw)
   return r;
 }
 
-// Texture::Sample(uvw, duvw, elliptic = true) (src/core/texture.cpp:32-52)
+// Texture::Sample(uvw, duvw, elliptic = true) (src/core/texture.cpp:32-52): the lookup itself plus 31 taps on the ellipse the
+// differentials span.  Everything that does not change from tap to tap is read ONCE here - the texture's kind, its size, where its
+// texels start (textureSample() above reads them per call: three dependent memory round trips per tap before the four texel loads) -
+// the kind is branched on outside the tap loop, the wrap-around of a texel index (integer divisions) sits behind one rarely taken
+// branch, and the tap offsets come through the scalar cache (the tap number is wave-uniform).  Same arithmetic per tap, same order
+// of the sum: same bits.
+typedef const __attribute__((address_space(4))) float *QaTapPtr;   // constant address space: uniform loads become s_load
+
+__device__ __forceinline__ f3 texCheckerAt(f3 c1, f3 c2, f3 uvw)
+{
+  const f3 u = tileClamp(uvw);
+  return ((u.x <= 0.5f) == (u.y <= 0.5f)) ? c1 : c2;
+}
+
+__device__ __forceinline__ f3 texBilinearAt(const float4 *data, int width, int height, f3 uvw)
+{
+  const f3 u = tileClamp(F3(uvw.x, 1.f - uvw.y, uvw.z));
+  const float x = width * u.x, y = height * u.y;
+  int ix = (int) x, iy = (int) y;
+  const float fx = x - ix, fy = y - iy;
+  if (__builtin_expect((unsigned) ix >= (unsigned) width || (unsigned) iy >= (unsigned) height, 0)) {
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+  }
+  int ixp = ix + 1;
+  if (ixp >= width) ixp -= width;
+  int iyp = iy + 1;
+  if (iyp >= height) iyp -= height;
+  f3 r = texel(data + (iy * width + ix)) * ((1 - fx) * (1 - fy));
+  r = r + texel(data + (iy * width + ixp)) * (fx * (1 - fy));
+  r = r + texel(data + (iyp * width + ix)) * ((1 - fx) * fy);
+  r = r + texel(data + (iyp * width + ixp)) * (fx * fy);
+  return r;
+}
+
 __device__ __forceinline__ f3 textureSampleFiltered(const TexTables &tt, int ti, f3 uvw, f3 d0, f3 d1)
 {
-  f3 c = textureSample(tt, ti, uvw);
-  if (dot(d0, d0) + dot(d1, d1) == 0) return c;
-  for (int i = 0; i < 31; ++i) {
-    const float x = tt.filter[2 * i], y = tt.filter[2 * i + 1];
-    c = c + textureSample(tt, ti, (uvw + d0 * x) + d1 * y);
+  const qa_texture &tx = tt.tex[ti];
+  const bool filtered = !(dot(d0, d0) + dot(d1, d1) == 0);
+  const QaTapPtr taps = (QaTapPtr) tt.filter;
+  f3 c;
+  if (tx.type == QA_TEX_CHECKER) {
+    const f3 c1 = ld3(tx.color1), c2 = ld3(tx.color2);
+    c = texCheckerAt(c1, c2, uvw);
+    if (filtered)
+      for (int i = 0; i < 31; ++i) c = c + texCheckerAt(c1, c2, (uvw + d0 * taps[2 * i]) + d1 * taps[2 * i + 1]);
+  } else {
+    const int width = tx.width, height = tx.height;
+    if (width + height == 0) return F3(0, 0, 0);    // (filtered: 32 zeros over 32)
+    const float4 *data = tt.texels + tt.texOff[ti];
+    c = texBilinearAt(data, width, height, uvw);
+    if (filtered)
+      for (int i = 0; i < 31; ++i) c = c + texBilinearAt(data, width, height, (uvw + d0 * taps[2 * i]) + d1 * taps[2 * i + 1]);
   }
-  return c / 32.f;
+  return filtered ? c / 32.f : c;
 }
 
 __device__ __forceinline__ f3 xformTo(const qa_texmap &m, f3 p) { return mulMV(m.itm, p - ld3(m.pos)); }

@@ -333,6 +333,37 @@ def test_exact_walks_alone_return_the_frame(scene):
     c.close()
 
 
+@pytest.mark.parametrize("scene", ["example_project3_sphere.xml", "example_project7_object.xml", "trc_scene_tower.xml", "trc_scene_xmas.xml",
+                                   "example_project10_test.xml", "custom_textures.xml"])
+def test_unwalked_shadow_rays_change_nothing(scene):
+    """A light whose term is zero in every component before its shadow factor (the surface faces away from it: cosNL = max(0, N.L)
+    = 0) adds that zero whether it is occluded or not: the product counts its shadow ray and does not walk it (directLight of
+    qa_kernel.h, csShadowBatch / the AREA replay of qa_kernel_cs.h).  Option "walk_zero_terms" walks them as the reference does:
+    same bits, same counters - LDS-resident, cooperative (textured, untextured, many lights, area lights) kernels; and the frame
+    is the counting kernel's (the reference's walk, every ray cast)."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 240, 136, 2
+    c = hip.Context(0)
+    c.upload_scene(load_scene_blob(scene, size=(w, h)))
+    c.reset_counters()
+    ref = c.render_region((0, 0, w, h), spp, stats=True)
+    ref_cnt = c.counters()
+    outs, cnts = {}, {}
+    for walk in (0, 1):
+        c.set_option("walk_zero_terms", walk)
+        c.reset_counters()
+        outs[walk] = c.render_region((0, 0, w, h), spp)
+        cnts[walk] = c.counters()
+    c.close()
+    for a, b, r in zip(outs[0], outs[1], ref):
+        assert np.array_equal(bits(a), bits(b))
+        assert np.array_equal(bits(a), bits(r))
+    for k in ("samples", "casts_normal", "casts_shadow", "pixels"):
+        assert cnts[0][k] == cnts[1][k] == ref_cnt[k], k
+
+
 def _write_area_lights_scene(path):
     """Two global-memory mesh instances, a sphere and a floor under an area point light, an area spot light, a plain point light and a
     direct light: every branch of the AREA variants' light replay."""
