@@ -160,7 +160,8 @@ int qa_set_pipeline(qa_ctx *ctx, int mode);
  *                    faces away from the light) is walked all the same, as the reference does; 0 (default) = counted, not walked
  *                    (same bits, same counters)
  *   "cs_pool_limit"  n > 0: upper bound for the pool of the cooperative walks (tests: forces the overflow path); 0 = none
- *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together
+ *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together; n >= 2 (cooperative
+ *                    kernel; elsewhere like 1): finished paths wait until n of the wave's have gathered
  *   "tile_order"     1 (default) / 0: tiles handed out centre-first
  *   "staged_groups"  1 (default) .. 8 tile groups of the staged pipeline, each on its own stream; more than one only pays
  *                    when the process started the HIP runtime with GPU_MAX_HW_QUEUES >= 8

@@ -110,6 +110,7 @@ static int SelectKernel(qa_ctx *c)
   // (any number of lights: their shadow queries are pooled QA_CS_LIGHT_BATCH = 4 lights at a time; with more than one batch the
   // surface waits in the slab DScene::csSurf between batches, qa_kernel_cs.h; area lights: the AREA variants)
   c->kernelCs = nullptr;
+  c->csMany = false;
   {
     const char *e = DevEnv("QA_COOP");
     int shadowLights = 0;
@@ -123,6 +124,7 @@ static int SelectKernel(qa_ctx *c)
       // untextured ones on scenes of more than 12 nodes (their register budget: see the kernel's comment)
       c->csCullVariant = c->csCullOk && (c->textured || c->ds.num_inst > 12);
       const bool many = shadowLights > QA_CS_LIGHT_BATCH && !c->area;   // (those variants always test the nodes' bounds)
+      c->csMany = many;
       if (many || c->area) c->csCullVariant = c->csCullOk;
       if (c->area)   // every light is evaluated when the path has ended, by the whole wave (qa_kernel_cs.h, AREA)
         c->kernelCs = c->textured ? (KernelFn) qa_integrate_cs<true, true, true, false, true> : (KernelFn) qa_integrate_cs<true, false, true, false, true>;
@@ -893,7 +895,6 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   rp.seed = seed;
   rp.tile_row0 = tile_row0; rp.tile_row_step = tile_row_step; rp.own_tile_rows = ownRows; rp.pad = 0;
   rp.sync_samples = c->syncSamples < 0 ? c->syncAuto : c->syncSamples;
-  if (c->kernelCs && c->area) rp.sync_samples = 1;   // the cooperative AREA variants evaluate a wave's lights between its samples
   rp.rgb = d_rgb; rp.depth = d_depth; rp.ns = d_ns;
   rp.work_counter = work;
   rp.tile_order = nullptr;
@@ -944,6 +945,11 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   DScene ds = c->ds;
   if (pmOn) ds.stackDepth = c->stackDepthPm;
   const bool cs = c->kernelCs && !pmOn && !(flags & QA_RENDER_STATS);
+  // the cooperative kernel's third way between "a lane starts its next sample at once" (0) and "when the whole wave is between samples"
+  // (1): a finished path waits until 32 of the wave's have gathered, then those lanes finish and start samples together.  Where 1 was
+  // the per-scene choice, and on scenes of many lights (an iteration is mostly their shadow batches), it beats both (experiments.txt 22)
+  if (cs && c->syncSamples < 0 && ((c->syncAuto && c->textured) || c->csMany)) rp.sync_samples = 32;   // (the variants that carry the code)
+  if (cs && c->area) rp.sync_samples = 1;   // the cooperative AREA variants evaluate a wave's lights between its samples
   ds.csCullOn = (c->optCsCull && c->csCullOk) ? 1u : 0u;
   ds.csForceExact = c->optCsForceExact;
   ds.walkZeroTerms = c->optWalkZeroTerms;
@@ -1348,7 +1354,7 @@ int qa_set_option(qa_ctx *c, const char *name, long long value)
   else if (n == "cs_force_exact") c->optCsForceExact = (uint32_t) (value & 3);
   else if (n == "walk_zero_terms") c->optWalkZeroTerms = value ? 1u : 0u;
   else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
-  else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value ? 1 : 0);
+  else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value > 64 ? 64 : (int) value);
   else if (n == "tile_order") c->tileOrder = value != 0;
   else if (n == "staged_groups") {
     c->wf.numGroups = (int) std::max<long long>(1, std::min<long long>(value, WfHost::kMaxGroups));

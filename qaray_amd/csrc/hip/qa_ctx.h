@@ -108,6 +108,7 @@ struct qa_ctx {
   void (*kernelStats)(const DScene, const RenderParams) = nullptr;
   bool resident = false, textured = false, area = false;
   int syncAuto = 0;
+  bool csMany = false;   // the cooperative kernel's MANY variant (more shadow-casting lights than one batch)
   bool tileOrder = true;        // centre-first tile order (QA_NO_TILE_ORDER=1 turns it off)
   uint32_t *dOrder = nullptr;   // tile launch order of the last region shape
   uint64_t orderKey = 0;

@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
   uint32_t pst = QA_PST_PRIMARY;
   bool alive = true, needPixel = true, needSample = false;
   uint32_t nrec = 0;       // AREA: hits logged for the current path
-  bool awaiting = false;   // AREA: the path has ended, its lights have not been evaluated yet
+  // BATCH (the textured and the many-light variants; compiled into the others it costs C4 and C5 1 %): sync_samples >= 2, below
+  constexpr bool BATCH = !AREA && (TEX || MANY);
+  bool awaiting = false;   // AREA: the path has ended, its lights have not been evaluated yet; BATCH: ... it waits for others to finish
 
   for (;;) {
     QA_T(tA)
@@ -1093,7 +1095,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     if (!__any(alive)) break;
 
     // ---- B. start a sample (qa_integrate, section B; src/renderers/renderer.cpp:312-328)
-    const bool goSample = !rp.sync_samples || (__ballot(needSample) == __ballot(alive && !needPixel));
+    const bool goSample = !rp.sync_samples || (BATCH && rp.sync_samples != 1) || (__ballot(needSample) == __ballot(alive && !needPixel));
     const bool starting = alive && needSample && goSample;
     cnt.samples += (unsigned long long) __popcll(__ballot(starting));   // (wave-uniform tallies: no registers per lane)
     if (starting) {
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     }
     QA_TACC(cnt.sl[1], tA)
     // ---- C. trace (qa_integrate, section C)
-    const bool act = alive && !needPixel && !needSample && !(AREA && awaiting);
+    const bool act = alive && !needPixel && !needSample && !((AREA || BATCH) && awaiting);
     bool done = false;
     Hit h;
     TexHit th;
@@ -1252,6 +1254,17 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       }
     }
 
+    // sync_samples >= 2: finished paths wait until that many of the wave's have gathered (or every lane's has): sections E and B
+    // then run for a group of lanes instead of a few lanes in nearly every iteration
+    if (BATCH && rp.sync_samples >= 2) {
+      awaiting = awaiting || (alive && done);
+      done = false;
+      const unsigned long long aw = __ballot(awaiting);
+      if (aw && (__popcll(aw) >= rp.sync_samples || aw == __ballot(alive && !needPixel))) {
+        done = awaiting;
+        awaiting = false;
+      }
+    }
     // ---- AREA: the lights of the paths that have ended, once the whole wave is between samples
     if (AREA) {
       awaiting = awaiting || (alive && done);

@@ -364,6 +364,30 @@ def test_unwalked_shadow_rays_change_nothing(scene):
         assert cnts[0][k] == cnts[1][k] == ref_cnt[k], k
 
 
+@pytest.mark.parametrize("scene", ["example_project7_object.xml", "trc_scene_tower.xml", "trc_scene_xmas.xml", "example_project3_sphere.xml"])
+def test_when_a_wave_starts_its_samples_changes_nothing(scene):
+    """Option "sync_samples": a lane starts its next sample at once (0), when the whole wave is between samples (1), or - cooperative
+    kernel - finished paths wait until n of the wave's have gathered (n >= 2; the per-scene default is 32 where it used to be 1).
+    Every pixel owns its random-number stream and its Halton index, so the frame and the counters are the same whichever it is."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    w, h, spp = 250, 130, 3   # (ragged tiles: lanes without a pixel sit beside waiting ones)
+    c = hip.Context(0)
+    c.upload_scene(load_scene_blob(scene, size=(w, h)))
+    outs, cnts = {}, {}
+    for v in (-1, 0, 1, 2, 8, 32, 64):
+        c.set_option("sync_samples", v)
+        c.reset_counters()
+        outs[v] = c.render_region((0, 0, w, h), spp)
+        cnts[v] = c.counters()
+    c.close()
+    for v in outs:
+        for a, b in zip(outs[v], outs[-1]):
+            assert np.array_equal(bits(a), bits(b)), v
+        assert all(cnts[v][k] == cnts[-1][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), v
+
+
 def _write_area_lights_scene(path):
     """Two global-memory mesh instances, a sphere and a floor under an area point light, an area spot light, a plain point light and a
     direct light: every branch of the AREA variants' light replay."""
