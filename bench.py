@@ -356,9 +356,10 @@ def main():
             limiter = ("latency of the LDS-resident tree walk (53 % of wave time on the Cornell box at 5 waves/SIMD; all correctly rounded div / sqrt "
                        "removed: +5.5 % only); not HBM bandwidth (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
         elif "qa_integrate_cs" in kernel_name:
-            limiter = ("latency: waves wait 36 - 54 % of their time (dependent node / ray-slot reads of the cooperative walks, the scene-graph sweeps' "
-                       "scalar loads, reloads of spilled registers) at ~40 % VALU issue; what the spilled registers cost once they leave the L2 is the "
-                       "first-order effect (DESIGN.md 5 round 3, profiles/round03/experiments.txt, sq_hbm_counters_16spp.txt); not HBM bandwidth")
+            limiter = ("latency: waves wait 30 - 50 % of their time (dependent node / ray-slot reads of the cooperative walks, reloads of spilled "
+                       "registers) at 38 - 48 % VALU issue; on scenes of few meshes the per-node arithmetic of the scene-graph sweeps (C4: 54 % of wave "
+                       "time, profiles/round03/stamps_cs_16spp.txt; their scalar loads are not it: experiments.txt 20); what the spilled registers "
+                       "cost once they leave the L2 is the first-order effect (DESIGN.md 5 round 3, sq_hbm_counters_16spp.txt); not HBM bandwidth")
         else:
             limiter = ("mesh walks in global memory at low lane occupancy and the dependent loads of the scene-graph loop; not HBM bandwidth, not "
                        "arithmetic (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
