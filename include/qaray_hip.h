@@ -162,6 +162,9 @@ int qa_set_pipeline(qa_ctx *ctx, int mode);
  *   "cs_pool_limit"  n > 0: upper bound for the pool of the cooperative walks (tests: forces the overflow path); 0 = none
  *   "sync_samples"   -1 (default: per scene) / 0 / 1: a wave starts the next samples of its 64 pixels together; n >= 2 (cooperative
  *                    kernel; elsewhere like 1): finished paths wait until n of the wave's have gathered
+ *   "chunk_spp"      -1 (default: per frame) / 0 / n: the per-lane kernels hand a tile's samples out in chunks - n samples first, then
+ *   "chunk_tail"     chunks of this many (0: an eighth of the frame's spp) - so that a frame of few tiles per wave ends on small work
+ *                    items; a pixel's state waits in device memory between chunks (same samples in the same order: same bits)
  *   "tile_order"     1 (default) / 0: tiles handed out centre-first
  *   "staged_groups"  1 (default) .. 8 tile groups of the staged pipeline, each on its own stream; more than one only pays
  *                    when the process started the HIP runtime with GPU_MAX_HW_QUEUES >= 8

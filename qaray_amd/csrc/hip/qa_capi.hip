@@ -965,6 +965,40 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
+  // ---- tiles in sample chunks (qa_kernel.h, section A): per-lane kernels only (the cooperative one keeps whole tiles: its frames
+  // have 8 - 32 tiles per wave).  Per frame: when a wave gets fewer than 16 tiles, a tile's samples are handed out in chunks, so that
+  // the frame ends on work items an eighth the size: half of them first, then eighths, where a wave's lanes start their samples
+  // together (they also reach a chunk's end together); three quarters first where they do not (every hand-over then waits for the
+  // tile's slowest pixel).  Cornell box 1080p @ 512 spp: 81.3 -> 72.5 ms (profiles/round03/chunk_sweep.txt).
+  rp.chunk_spp = 0; rp.chunk_tail = 0; rp.num_chunks = 1; rp.chunk_pad = 0; rp.tile_progress = nullptr; rp.pix_state = nullptr;
+  if (!cs && !(c->wf.mode == QA_PIPE_STAGED) && c->optChunkSpp != 0) {
+    uint32_t chunk = 0, tail = 0;
+    if (c->optChunkSpp > 0) chunk = (uint32_t) c->optChunkSpp;
+    else if ((long long) tiles < 16 * blocks * (QA_BLOCK / 64) && (long long) tiles >= blocks * (QA_BLOCK / 64) && spp_max >= 64)
+      chunk = rp.sync_samples ? (uint32_t) spp_max / 2u : (uint32_t) spp_max - (uint32_t) spp_max / 4u;
+    tail = c->optChunkTail > 0 ? (uint32_t) c->optChunkTail : std::max(16u, (uint32_t) spp_max / 8u);
+    if (chunk > 0 && chunk < (uint32_t) spp_max) {
+      const uint32_t nChunks = 1u + ((uint32_t) spp_max - chunk + tail - 1) / tail;
+      if ((unsigned long long) tiles * 64ull * nChunks < 0xFFFF0000ull) {
+        const size_t needState = (size_t) tiles * 64 * 8, needProg = tiles;
+        if (needState > c->pixStateWords) {
+          if (c->dPixState) { HIP_TRY(hipDeviceSynchronize()); (void) hipFree(c->dPixState); c->dPixState = nullptr; c->pixStateWords = 0; }
+          HIP_TRY(hipMalloc((void **) &c->dPixState, needState * sizeof(uint32_t)));
+          c->pixStateWords = needState;
+        }
+        if (needProg > c->tileProgressWords) {
+          if (c->dTileProgress) { HIP_TRY(hipDeviceSynchronize()); (void) hipFree(c->dTileProgress); c->dTileProgress = nullptr; c->tileProgressWords = 0; }
+          HIP_TRY(hipMalloc((void **) &c->dTileProgress, needProg * sizeof(uint32_t)));
+          c->tileProgressWords = needProg;
+        }
+        if (!c->chunkEv) HIP_TRY(hipEventCreateWithFlags(&c->chunkEv, hipEventDisableTiming));
+        if (c->chunkEvSet) HIP_TRY(hipStreamWaitEvent(s, c->chunkEv, 0));   // (one pair of slabs per context: frames on other streams wait)
+        HIP_TRY(hipMemsetAsync(c->dTileProgress, 0, needProg * sizeof(uint32_t), s));
+        rp.chunk_spp = chunk; rp.chunk_tail = tail; rp.num_chunks = nChunks; rp.tile_progress = c->dTileProgress; rp.pix_state = c->dPixState;
+      }
+    }
+  }
+
   // ---- which integrator: both return the same bits.  The staged one (qa_wf.h) runs on request only (QA_PIPE_STAGED): since
   // the cooperative walks the megakernel is the faster one on every scene measured, and round 2's timed probe between the
   // two is gone.
@@ -981,6 +1015,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   } else {
     hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
     HIP_TRY(hipGetLastError());
+    if (rp.chunk_spp) { HIP_TRY(hipEventRecord(c->chunkEv, s)); c->chunkEvSet = true; }
   }
   HIP_TRY(hipEventRecord(ev.b, s));
   {
@@ -1137,6 +1172,9 @@ int qa_ctx_destroy(qa_ctx *c)
   if (c->dHalton) (void) hipFree(c->dHalton);
   if (c->dOrder) (void) hipFree(c->dOrder);
   if (c->dWork) (void) hipFree(c->dWork);
+  if (c->dPixState) (void) hipFree(c->dPixState);
+  if (c->dTileProgress) (void) hipFree(c->dTileProgress);
+  if (c->chunkEv) (void) hipEventDestroy(c->chunkEv);
   if (c->dCounters) (void) hipFree(c->dCounters);
   if (c->hStop) (void) hipHostFree(c->hStop);
   if (c->dRgb) (void) hipFree(c->dRgb);
@@ -1353,6 +1391,8 @@ int qa_set_option(qa_ctx *c, const char *name, long long value)
   } else if (n == "cs_cull") c->optCsCull = value != 0;
   else if (n == "cs_force_exact") c->optCsForceExact = (uint32_t) (value & 3);
   else if (n == "walk_zero_terms") c->optWalkZeroTerms = value ? 1u : 0u;
+  else if (n == "chunk_spp") c->optChunkSpp = value < 0 ? -1 : (int) (value > 65535 ? 65535 : value);
+  else if (n == "chunk_tail") c->optChunkTail = value < 0 ? 0 : (int) (value > 65535 ? 65535 : value);
   else if (n == "cs_pool_limit") c->optCsPool = value > 0 ? (uint32_t) std::max<long long>(64, value) : 0u;
   else if (n == "sync_samples") c->syncSamples = value < 0 ? -1 : (value > 64 ? 64 : (int) value);
   else if (n == "tile_order") c->tileOrder = value != 0;

@@ -1408,8 +1408,17 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
   // src/renderers/renderer.cpp:383-387); its outputs are packed strip after strip.
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
-  const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
+  // Tiles in sample chunks (RenderParams::chunk_spp): a frame of few tiles per wave ends with waves idle while the last tiles finish
+  // their hundreds of samples (1080p at 512 spp on 5 120 waves: 6.3 tiles of ~12 ms per wave, 11 % of the wave slots empty on
+  // average).  A pixel's samples cannot be shared out - one random-number stream, one running variance - but they can be HANDED ON:
+  // a work item is (chunk, tile), all tiles' chunk 0 first; at the end of a chunk every lane stores its pixel's state, the wave
+  // publishes the tile's progress (agent-scope release), and whoever fetches (chunk + 1, tile) - a whole pass of the frame later -
+  // reads the state back behind an acquire.  Same samples in the same order for every pixel: same bits.
+  const unsigned numTiles = tilesX * (unsigned) rp.own_tile_rows;
+  const unsigned total = numTiles * (rp.chunk_spp ? rp.num_chunks : 1u) * 64u;
   const unsigned lane = __lane_id();
+  unsigned curTile = 0xFFFFFFFFu, curChunk = 0;   // (wave-uniform) the work item in hand
+  int chunkEnd = 0x7FFFFFFF;                      // samples a pixel has when its chunk is complete
 
   DCounters cnt = {};
 #ifdef QA_STAMPS
@@ -1458,17 +1467,43 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
     const unsigned long long aliveMask = __ballot(alive);
     const unsigned long long want = __ballot(alive && needPixel);
     if (want && want == aliveMask) {
+      if (rp.chunk_spp && curTile != 0xFFFFFFFFu) {
+        // the chunk in hand is complete: every lane has stored its pixel's state (section E); publish it
+        // (the state words are agent-scope atomic stores - written through, no line of them stays in this XCD's L2 - and this wave
+        // has waited for all of them: no release fence, whose write-back of the L2's dirty lines - the spilled registers of every
+        // wave of the XCD - cost 170 us per hand-over; MI355X_MICROARCH.md, inter-workgroup visibility)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(rp.tile_progress + curTile, curChunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        curTile = 0xFFFFFFFFu;
+      }
       unsigned base = 0;
       const int leader = __ffsll((long long) want) - 1;
       if ((int) lane == leader) base = (*rp.stop_flag) ? total : atomicAdd(rp.work_counter, 64u);
       base = __shfl(base, leader);
+      unsigned item = base / 64;   // (wave-uniform) tile, or chunk * numTiles + tile
+      if (rp.chunk_spp && base < total) {
+        curChunk = item / numTiles;
+        item -= curChunk * numTiles;
+        curTile = item;
+        chunkEnd = (int) (rp.chunk_spp + curChunk * rp.chunk_tail);
+        if (curChunk > 0) {
+          // the tile's previous chunk was handed out a whole pass of the frame ago: this wait ends at once, except on frames of
+          // fewer tiles than waves.  Its holder is a resident wave that waits for nothing this wave holds; the bound is a guard
+          // against a lost update, not a path that is taken (a frame that hit it would fail every parity test).
+          for (int spins = 0; spins < (1 << 22); ++spins) {
+            if (__hip_atomic_load(rp.tile_progress + curTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= curChunk) break;
+            __builtin_amdgcn_s_sleep(16);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
       if (alive) {
         const unsigned w = base + lane;
         if (base >= total) {
           alive = false;
         } else {
           const unsigned in = w % 64;
-          const unsigned tile = rp.tile_order ? rp.tile_order[w / 64] : w / 64;
+          const unsigned tile = rp.tile_order ? rp.tile_order[item] : item;
           const unsigned otr = tile / tilesX;  // index among the strips this launch owns
           const unsigned tx = (tile % tilesX) * 8 + (in % 8);
           const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
@@ -1478,14 +1513,31 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
             q = (otr * 8 + (in / 8)) * (unsigned) rw + tx;
             rng = qa_pixel_seed(rp.seed, (uint32_t) py * (uint32_t) sc.cam.width + (uint32_t) px);
             sidx = 0;
-            if (LCOLS) {
-              acc[12 * QA_BLOCK] = __uint_as_float((unsigned) px | ((unsigned) py << 16));
-              acc[13 * QA_BLOCK] = __uint_as_float(q);
-              acc[14 * QA_BLOCK] = __int_as_float(0);
-            }
             for (int i = 0; i < 6; ++i) acc[i * QA_BLOCK] = 0.f;
             needSample = true;
             needPixel = false;
+            if (rp.chunk_spp && curChunk > 0) {
+              // the pixel as the previous chunk left it
+              const unsigned long long *st = reinterpret_cast<const unsigned long long *>(rp.pix_state) + 4 * (size_t) q;
+              const unsigned long long s0 = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       s2 = __hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s3 = __hip_atomic_load(st + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint4 a = make_uint4((uint32_t) s0, (uint32_t) (s0 >> 32), (uint32_t) s1, (uint32_t) (s1 >> 32));
+              const uint4 b = make_uint4((uint32_t) s2, (uint32_t) (s2 >> 32), (uint32_t) s3, (uint32_t) (s3 >> 32));
+              if (a.y & 0x80000000u) {   // finished in an earlier chunk: the lane sits this one out
+                needSample = false;
+                needPixel = true;
+              } else {
+                rng = a.x;
+                sidx = (int) a.y;
+                acc[0] = __uint_as_float(a.z); acc[QA_BLOCK] = __uint_as_float(a.w); acc[2 * QA_BLOCK] = __uint_as_float(b.x);
+                acc[3 * QA_BLOCK] = __uint_as_float(b.y); acc[4 * QA_BLOCK] = __uint_as_float(b.z); acc[5 * QA_BLOCK] = __uint_as_float(b.w);
+              }
+            }
+            if (LCOLS) {
+              acc[12 * QA_BLOCK] = __uint_as_float((unsigned) px | ((unsigned) py << 16));
+              acc[13 * QA_BLOCK] = __uint_as_float(q);
+              acc[14 * QA_BLOCK] = __int_as_float(sidx);
+            }
           }
           // else: padding slot of a ragged tile - this lane sits the tile out
         }
@@ -1682,12 +1734,26 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       const bool more = sidx < rp.spp_min ||
                         (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
-        needSample = true;
+        if (rp.chunk_spp && sidx >= chunkEnd) {
+          // the chunk's last sample of this pixel: its state waits for whoever takes the tile's next chunk
+          unsigned long long *st = reinterpret_cast<unsigned long long *>(rp.pix_state) + 4 * (size_t) qo;
+#define QA_PAIR(lo, hi) ((unsigned long long) (lo) | ((unsigned long long) (hi) << 32))
+          __hip_atomic_store(st, QA_PAIR(rng, (uint32_t) sidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(st + 1, QA_PAIR(__float_as_uint(mean.x), __float_as_uint(mean.y)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(st + 2, QA_PAIR(__float_as_uint(mean.z), __float_as_uint(cstd.x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(st + 3, QA_PAIR(__float_as_uint(cstd.y), __float_as_uint(cstd.z)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef QA_PAIR
+          needPixel = true;
+        } else {
+          needSample = true;
+        }
       } else {
         rp.rgb[3 * qo + 0] = mean.x;
         rp.rgb[3 * qo + 1] = mean.y;
         rp.rgb[3 * qo + 2] = mean.z;
         rp.ns[qo] = (uint32_t) sidx;
+        if (rp.chunk_spp)   // (later chunks of the tile skip this pixel)
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(rp.pix_state) + 4 * (size_t) qo, 0x80000000ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         QA_TALLY(cnt.pixels);
         needPixel = true;
       }

@@ -257,6 +257,12 @@ struct RenderParams {
   unsigned int *work_counter;  // next work item (pixel) of this launch
   const volatile int *stop_flag;
   DCounters *counters;
+  // Tiles in sample chunks (qa_integrate, section A): chunk_spp > 0 = a work item is (chunk, tile) - a tile's pixels for chunk_spp
+  // samples; a pixel's state between chunks (RNG state, samples taken | finished flag, running mean and variance: 8 words) waits in
+  // pix_state[8 x output index], tile_progress[tile] = chunks of the tile that are complete (zeroed before the launch)
+  uint32_t chunk_spp, chunk_tail, num_chunks, chunk_pad;   // the first chunk's samples, every further chunk's, how many chunks
+  uint32_t *tile_progress;
+  uint32_t *pix_state;
   // PHOTON kernel variants (Scene::usePhotonMap): [0] photon map, [1] caustics map, and the per-lane
   // nearest-photon heaps ([grid threads][QA_PHOTON_GATHER + 1] x (distance^2, photon index))
   DPhotonMap pm[2];

@@ -248,7 +248,7 @@ class Context:
         _check(lib().qa_set_pipeline(self._h, self.PIPELINES[mode]))
 
     def set_option(self, name, value):
-        """qa_set_option: 'coop', 'cs_cull', 'cs_force_exact', 'walk_zero_terms', 'cs_pool_limit', 'sync_samples', 'tile_order', 'staged_groups', 'verbose'."""
+        """qa_set_option: 'coop', 'cs_cull', 'cs_force_exact', 'walk_zero_terms', 'cs_pool_limit', 'chunk_spp', 'chunk_tail', 'sync_samples', 'tile_order', 'staged_groups', 'verbose'."""
         _check(lib().qa_set_option(self._h, name.encode(), int(value)))
 
     def kernel_name(self):

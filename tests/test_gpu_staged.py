@@ -388,6 +388,42 @@ def test_when_a_wave_starts_its_samples_changes_nothing(scene):
         assert all(cnts[v][k] == cnts[-1][k] for k in ("samples", "casts_normal", "casts_shadow", "pixels")), v
 
 
+@pytest.mark.parametrize("scene,coop", [("example_project12_box.xml", 1), ("example_project3_sphere.xml", 1), ("trc_mtl_glass.xml", 1),
+                                        ("custom_photon.xml", 1), ("example_project10_test.xml", 0), ("example_project7_object.xml", 0)])
+def test_tiles_in_sample_chunks_change_nothing(scene, coop):
+    """Options "chunk_spp" / "chunk_tail": the per-lane kernels hand a tile's samples out in chunks (a pixel's RNG state, sample count and
+    running mean / variance wait in device memory between chunks; the tile's next chunk may be taken by any wave, which waits for the
+    previous one to be published).  Same samples in the same order for every pixel: same bits, counters and sample counts - with
+    adaptive sampling (pixels finish in different chunks), ragged tiles, far fewer tiles than waves (every hand-over is waited for)
+    and frames of many tiles; LDS-resident, global-memory (coop = 0), textured and area-light variants; and the counting
+    kernel of a chunked frame equals the unchunked one."""
+    from qaray_amd import hip
+    from qaray_amd.host import load_scene_blob
+    ensure_assets()
+    c = hip.Context(0)
+    c.set_option("coop", coop)
+    for (w, h, spp_min, spp_max) in ((250, 130, 3, 40), (640, 360, 24, 24)):
+        c.upload_scene(load_scene_blob(scene, size=(w, h)))
+        outs, cnts = {}, {}
+        for chunk, tail in ((0, 0), (-1, 0), (16, 8), (1, 1), (8, 16), (23, 5)):
+            c.set_option("chunk_spp", chunk)
+            c.set_option("chunk_tail", tail)
+            c.reset_counters()
+            outs[(chunk, tail)] = c.render_region((0, 0, w, h), spp_min, spp_max=spp_max)
+            cnts[(chunk, tail)] = c.counters()
+            assert "qa_integrate<" in c.kernel_name(), c.kernel_name()
+        c.set_option("chunk_spp", 7)
+        c.set_option("chunk_tail", 3)
+        stats = c.render_region((0, 0, w, h), spp_min, spp_max=spp_max, stats=True)
+        for k in outs:
+            for a, b in zip(outs[k], outs[(0, 0)]):
+                assert np.array_equal(bits(a), bits(b)), k
+            assert all(cnts[k][n] == cnts[(0, 0)][n] for n in ("samples", "casts_normal", "casts_shadow", "pixels")), k
+        for a, b in zip(stats, outs[(0, 0)]):
+            assert np.array_equal(bits(a), bits(b))
+    c.close()
+
+
 def _write_area_lights_scene(path):
     """Two global-memory mesh instances, a sphere and a floor under an area point light, an area spot light, a plain point light and a
     direct light: every branch of the AREA variants' light replay."""
