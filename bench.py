@@ -353,8 +353,9 @@ def main():
             limiter = ("critical path of the four stage kernels of a pass (launch ramp + the longest mesh walks while the chip drains), several "
                        "chains in flight; not HBM bandwidth, not arithmetic (profiles/round02/staged_timeline_16spp.txt, session3_experiments.txt)")
         elif "RES=1" in kernel_name:
-            limiter = ("latency of the LDS-resident tree walk (53 % of wave time on the Cornell box at 5 waves/SIMD; all correctly rounded div / sqrt "
-                       "removed: +5.5 % only); not HBM bandwidth (profiles/round02/megakernel_section_stamps.txt, session3_experiments.txt)")
+            limiter = ("VALU issue (55 % of the SIMD cycles) at 57 % lane utilisation - the divergence of the per-lane tree walks (LDS-resident tree: "
+                       "53 % of wave time; all correctly rounded div / sqrt removed: +5.5 % only); the wave slots are occupied 98.6 % of the kernel "
+                       "since a tile's samples are handed out in chunks (88.6 % before: profiles/round03/experiments.txt 27); not HBM bandwidth")
         elif "qa_integrate_cs" in kernel_name:
             limiter = ("latency: waves wait 30 - 50 % of their time (dependent node / ray-slot reads of the cooperative walks, reloads of spilled "
                        "registers) at 38 - 48 % VALU issue; on scenes of few meshes the per-node arithmetic of the scene-graph sweeps (C4: 54 % of wave "
