@@ -113,6 +113,14 @@ def test_photon_maps_on_large_scenes_against_oracle(ctx, scene, pm, cm):
     o_rgb, o_depth, o_ns, _ = oracle.render(blob, (0, 0, w, h), spp, photon=(pp, o_pm, o_cm))
     assert np.array_equal(bits(depth), bits(o_depth)) and np.array_equal(ns, o_ns)
     assert float(np.abs(rgb - o_rgb).max()) <= REL_MAX_TOL * max(1.0, float(np.abs(o_rgb).max()))
+    # a tile's samples handed out in chunks (options chunk_spp / chunk_tail, qa_kernel.h section A): the PHOTON variants too
+    ctx.set_option("chunk_spp", 1)
+    ctx.set_option("chunk_tail", 1)
+    again = ctx.render_region((0, 0, w, h), spp)
+    ctx.set_option("chunk_spp", -1)
+    ctx.set_option("chunk_tail", 0)
+    for a, b in zip(again, (rgb, depth, ns)):
+        assert np.array_equal(bits(a), bits(b))
     ctx.clear_photon_maps()
 
 
