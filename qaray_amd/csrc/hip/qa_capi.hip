@@ -965,13 +965,13 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   if (blocks > needBlocks) blocks = needBlocks;
   if (blocks < 1) blocks = 1;
 
-  // ---- tiles in sample chunks (qa_kernel.h, section A): per-lane kernels only (the cooperative one keeps whole tiles: its frames
-  // have 8 - 32 tiles per wave).  Per frame: when a wave gets fewer than 16 tiles, a tile's samples are handed out in chunks, so that
+  // ---- tiles in sample chunks (qa_kernel.h, section A): the per-lane kernels and the cooperative kernel's textured variants (in the
+  // untextured ones the code costs more than their 4K frames' tails: 31 tiles per wave).  Per frame: when a wave gets fewer than 16 tiles, a tile's samples are handed out in chunks, so that
   // the frame ends on work items an eighth the size: half of them first, then eighths, where a wave's lanes start their samples
   // together (they also reach a chunk's end together); three quarters first where they do not (every hand-over then waits for the
   // tile's slowest pixel).  Cornell box 1080p @ 512 spp: 81.3 -> 72.5 ms (profiles/round03/chunk_sweep.txt).
   rp.chunk_spp = 0; rp.chunk_tail = 0; rp.num_chunks = 1; rp.chunk_pad = 0; rp.tile_progress = nullptr; rp.pix_state = nullptr;
-  if (!cs && !(c->wf.mode == QA_PIPE_STAGED) && c->optChunkSpp != 0) {
+  if ((!cs || c->textured) && !(c->wf.mode == QA_PIPE_STAGED) && c->optChunkSpp != 0) {   // (cooperative kernel: the textured variants carry the code)
     uint32_t chunk = 0, tail = 0;
     if (c->optChunkSpp > 0) chunk = (uint32_t) c->optChunkSpp;
     else if ((long long) tiles < 16 * blocks * (QA_BLOCK / 64) && (long long) tiles >= blocks * (QA_BLOCK / 64) && spp_max >= 64)

@@ -966,6 +966,47 @@ __device__ __forceinline__ f3 csLightSum(f3 sum, const CsTerms &t, uint32_t nb, 
 // changes the register allocation of qa_integrate's LDS-resident variants - the Cornell-box kernel lost 8 % (13.0 -> 12.0
 // Gsamples/s) with only the tile fetch factored out (profiles/round02/session3_experiments.txt, item 14).
 // ---------------------------------------------------------------------------------------------
+// Tiles in sample chunks (qa_integrate, section A; RenderParams::chunk_spp): the rare steps out of line - compiled into the kernel's
+// text they cost the textured variant 47 spilled registers (experiments.txt 28).
+// The wait for a tile's previous chunk and what the chunk is: -> samples a pixel has when this chunk is complete.
+__device__ __attribute__((noinline)) int csChunkBegin(uint32_t *progress, uint32_t tile, uint32_t chunk, uint32_t first, uint32_t tail)
+{
+  if (chunk > 0) {
+    for (int spins = 0; spins < (1 << 22); ++spins) {   // (ends at once except on frames of fewer tiles than waves)
+      if (__hip_atomic_load(progress + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chunk) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  return (int) (first + chunk * tail);
+}
+// A pixel as the previous chunk left it: columns 0 - 5 and 14 of the lane (mean, variance, samples taken); -> RNG state, or 0 with
+// *finished set when the pixel finished in an earlier chunk
+__device__ __attribute__((noinline)) uint32_t csChunkRestore(const uint32_t *state, uint32_t q, float *acc, bool *finished)
+{
+  const unsigned long long *st = reinterpret_cast<const unsigned long long *>(state) + 4 * (size_t) q;
+  const unsigned long long s0 = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           s2 = __hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s3 = __hip_atomic_load(st + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *finished = ((uint32_t) (s0 >> 32) & 0x80000000u) != 0;
+  if (*finished) return 0;
+  acc[14 * 64] = __uint_as_float((uint32_t) (s0 >> 32));
+  acc[0] = __uint_as_float((uint32_t) s1); acc[64] = __uint_as_float((uint32_t) (s1 >> 32)); acc[2 * 64] = __uint_as_float((uint32_t) s2);
+  acc[3 * 64] = __uint_as_float((uint32_t) (s2 >> 32)); acc[4 * 64] = __uint_as_float((uint32_t) s3); acc[5 * 64] = __uint_as_float((uint32_t) (s3 >> 32));
+  return (uint32_t) s0;
+}
+// ... and as this chunk leaves it (sidx with bit 31: finished)
+__device__ __attribute__((noinline)) void csChunkSave(uint32_t *state, uint32_t q, uint32_t rng, uint32_t sidx, const float *acc)
+{
+  unsigned long long *st = reinterpret_cast<unsigned long long *>(state) + 4 * (size_t) q;
+#define QA_PAIR(lo, hi) ((unsigned long long) (lo) | ((unsigned long long) (hi) << 32))
+  __hip_atomic_store(st, QA_PAIR(rng, sidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (sidx & 0x80000000u) return;
+  __hip_atomic_store(st + 1, QA_PAIR(__float_as_uint(acc[0]), __float_as_uint(acc[64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(st + 2, QA_PAIR(__float_as_uint(acc[2 * 64]), __float_as_uint(acc[3 * 64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(st + 3, QA_PAIR(__float_as_uint(acc[4 * 64]), __float_as_uint(acc[5 * 64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef QA_PAIR
+}
+
 #ifndef QA_CS_WAVES_NOTEX
 #define QA_CS_WAVES_NOTEX 4
 #endif
@@ -1030,7 +1071,13 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
 
   const int rw = rp.x1 - rp.x0, rh = rp.y1 - rp.y0;
   const unsigned tilesX = (unsigned) (rw + 7) / 8;
-  const unsigned total = tilesX * (unsigned) rp.own_tile_rows * 64u;
+  // tiles in sample chunks (qa_integrate, section A: RenderParams::chunk_spp)
+  const unsigned numTiles = tilesX * (unsigned) rp.own_tile_rows;
+  // (in the textured variants only: C3 + 2.3 %, project9 + 2.4 %; the untextured ones - C4, C5: 31 tiles per wave - lose 2 % to the code alone)
+  constexpr bool CHUNK = TEX;
+  const unsigned total = numTiles * ((CHUNK && rp.chunk_spp) ? rp.num_chunks : 1u) * 64u;
+  unsigned curTile = 0xFFFFFFFFu, curChunk = 0;   // (wave-uniform) the work item in hand
+  int chunkEnd = 0x7FFFFFFF;                      // samples a pixel has when its chunk is complete
 
   DCounters cnt = {};
 #ifdef QA_STAMPS
@@ -1065,17 +1112,30 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     const unsigned long long aliveMask = __ballot(alive);
     const unsigned long long want = __ballot(alive && needPixel);
     if (want && want == aliveMask) {
+      if (CHUNK && rp.chunk_spp && curTile != 0xFFFFFFFFu) {
+        // the chunk in hand is complete: every lane's state words (agent-scope atomic stores, section E) have been waited for; publish
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(rp.tile_progress + curTile, curChunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        curTile = 0xFFFFFFFFu;
+      }
       unsigned base = 0;
       const int leader = __ffsll((long long) want) - 1;
       if ((int) lane == leader) base = (*rp.stop_flag) ? total : atomicAdd(rp.work_counter, 64u);
       base = __shfl(base, leader);
+      unsigned item = base / 64;   // (wave-uniform) tile, or chunk * numTiles + tile
+      if (CHUNK && rp.chunk_spp && base < total) {
+        curChunk = item / numTiles;
+        item -= curChunk * numTiles;
+        curTile = item;
+        chunkEnd = csChunkBegin(rp.tile_progress, curTile, curChunk, rp.chunk_spp, rp.chunk_tail);
+      }
       if (alive) {
         const unsigned w = base + lane;
         if (base >= total) {
           alive = false;
         } else {
           const unsigned in = w % 64;
-          const unsigned tile = rp.tile_order ? rp.tile_order[w / 64] : w / 64;
+          const unsigned tile = rp.tile_order ? rp.tile_order[item] : item;
           const unsigned otr = tile / tilesX;
           const unsigned tx = (tile % tilesX) * 8 + (in % 8);
           const unsigned ty = ((unsigned) rp.tile_row0 + otr * (unsigned) rp.tile_row_step) * 8 + (in / 8);
@@ -1088,6 +1148,12 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
             for (int i = 0; i < 6; ++i) acc[i * 64] = 0.f;
             needSample = true;
             needPixel = false;
+            if (CHUNK && rp.chunk_spp && curChunk > 0) {
+              bool finished;
+              const uint32_t r = csChunkRestore(rp.pix_state, QA_Q(), acc, &finished);
+              if (finished) { needSample = false; needPixel = true; }   // (finished in an earlier chunk: the lane sits this one out)
+              else rng = r;
+            }
           }
         }
       }
@@ -1385,13 +1451,19 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       acc[14 * 64] = __int_as_float(sidx);
       const bool more = sidx < rp.spp_min || (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
-        needSample = true;
+        if (CHUNK && rp.chunk_spp && sidx >= chunkEnd) {
+          csChunkSave(rp.pix_state, QA_Q(), rng, (uint32_t) sidx, acc);   // the chunk's last sample of this pixel: its state waits for the next chunk's wave
+          needPixel = true;
+        } else {
+          needSample = true;
+        }
       } else {
         const uint32_t q = QA_Q();
         rp.rgb[3 * q + 0] = mean.x;
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
         rp.ns[q] = (uint32_t) sidx;
+        if (CHUNK && rp.chunk_spp) csChunkSave(rp.pix_state, q, 0u, 0x80000000u, acc);   // (later chunks of the tile skip this pixel)
         pixelDone = true;
         needPixel = true;
       }

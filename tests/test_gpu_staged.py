@@ -389,9 +389,10 @@ def test_when_a_wave_starts_its_samples_changes_nothing(scene):
 
 
 @pytest.mark.parametrize("scene,coop", [("example_project12_box.xml", 1), ("example_project3_sphere.xml", 1), ("trc_mtl_glass.xml", 1),
-                                        ("custom_photon.xml", 1), ("example_project10_test.xml", 0), ("example_project7_object.xml", 0)])
+                                        ("custom_photon.xml", 1), ("example_project10_test.xml", 0), ("example_project7_object.xml", 0),
+                                        ("example_project7_object.xml", 1), ("example_project10_test.xml", 1), ("example_project9.xml", 1)])
 def test_tiles_in_sample_chunks_change_nothing(scene, coop):
-    """Options "chunk_spp" / "chunk_tail": the per-lane kernels hand a tile's samples out in chunks (a pixel's RNG state, sample count and
+    """Options "chunk_spp" / "chunk_tail": the per-lane kernels and the cooperative kernel's textured variants hand a tile's samples out in chunks (a pixel's RNG state, sample count and
     running mean / variance wait in device memory between chunks; the tile's next chunk may be taken by any wave, which waits for the
     previous one to be published).  Same samples in the same order for every pixel: same bits, counters and sample counts - with
     adaptive sampling (pixels finish in different chunks), ragged tiles, far fewer tiles than waves (every hand-over is waited for)
@@ -411,7 +412,7 @@ def test_tiles_in_sample_chunks_change_nothing(scene, coop):
             c.reset_counters()
             outs[(chunk, tail)] = c.render_region((0, 0, w, h), spp_min, spp_max=spp_max)
             cnts[(chunk, tail)] = c.counters()
-            assert "qa_integrate<" in c.kernel_name(), c.kernel_name()
+            assert ("qa_integrate_cs<" in c.kernel_name()) == (coop == 1 and scene.startswith("example_project") and "sphere" not in scene and "box" not in scene), c.kernel_name()
         c.set_option("chunk_spp", 7)
         c.set_option("chunk_tail", 3)
         stats = c.render_region((0, 0, w, h), spp_min, spp_max=spp_max, stats=True)
