@@ -889,6 +889,10 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   c->workNext = (c->workNext + 1) % qa_ctx::kCounterRing;
   HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned int), s));
 
+  // one frame at a time per context (its device slabs are one per context): a frame on another stream than the last one waits for it
+  if (!c->chunkEv) HIP_TRY(hipEventCreateWithFlags(&c->chunkEv, hipEventDisableTiming));
+  if (c->chunkEvSet && s != c->lastStream) HIP_TRY(hipStreamWaitEvent(s, c->chunkEv, 0));
+
   RenderParams rp;
   rp.x0 = x0; rp.y0 = y0; rp.x1 = x1; rp.y1 = y1;
   rp.spp_min = spp_min; rp.spp_max = spp_max; rp.max_bounce = max_bounce;
@@ -991,8 +995,6 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
           HIP_TRY(hipMalloc((void **) &c->dTileProgress, needProg * sizeof(uint32_t)));
           c->tileProgressWords = needProg;
         }
-        if (!c->chunkEv) HIP_TRY(hipEventCreateWithFlags(&c->chunkEv, hipEventDisableTiming));
-        if (c->chunkEvSet) HIP_TRY(hipStreamWaitEvent(s, c->chunkEv, 0));   // (one pair of slabs per context: frames on other streams wait)
         HIP_TRY(hipMemsetAsync(c->dTileProgress, 0, needProg * sizeof(uint32_t), s));
         rp.chunk_spp = chunk; rp.chunk_tail = tail; rp.num_chunks = nChunks; rp.tile_progress = c->dTileProgress; rp.pix_state = c->dPixState;
       }
@@ -1015,8 +1017,10 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
   } else {
     hipLaunchKernelGGL(kernel, dim3((unsigned) blocks), dim3(QA_BLOCK), (unsigned) ldsBytes, s, ds, rp);
     HIP_TRY(hipGetLastError());
-    if (rp.chunk_spp) { HIP_TRY(hipEventRecord(c->chunkEv, s)); c->chunkEvSet = true; }
   }
+  HIP_TRY(hipEventRecord(c->chunkEv, s));
+  c->chunkEvSet = true;
+  c->lastStream = s;
   HIP_TRY(hipEventRecord(ev.b, s));
   {
     // the kernel this frame really ran on

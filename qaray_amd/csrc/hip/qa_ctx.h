@@ -94,8 +94,9 @@ struct qa_ctx {
   // tiles in sample chunks (qa_integrate, RenderParams::chunk_spp): per-pixel state between chunks, per-tile progress
   uint32_t *dPixState = nullptr, *dTileProgress = nullptr;
   size_t pixStateWords = 0, tileProgressWords = 0;
-  hipEvent_t chunkEv = nullptr;   // end of the last chunked launch: the slabs are one per context
+  hipEvent_t chunkEv = nullptr;   // end of the last frame: the slabs (this one, the area-light log, the many-light surface slab) are one per context
   bool chunkEvSet = false;
+  hipStream_t lastStream = nullptr;   // ... a frame on another stream waits for it
   int optChunkSpp = -1;           // "chunk_spp": -1 per frame (few tiles per wave), 0 off, n samples of a tile's first chunk
   int optChunkTail = 0;           // "chunk_tail": samples of every further chunk (0: an eighth of the frame's spp)
   int workNext = 0;
