@@ -983,7 +983,7 @@ static int Render(qa_ctx *c, int x0, int y0, int x1, int y1, int tile_row0, int 
     tail = c->optChunkTail > 0 ? (uint32_t) c->optChunkTail : std::max(16u, (uint32_t) spp_max / 8u);
     if (chunk > 0 && chunk < (uint32_t) spp_max) {
       const uint32_t nChunks = 1u + ((uint32_t) spp_max - chunk + tail - 1) / tail;
-      if ((unsigned long long) tiles * 64ull * nChunks < 0xFFFF0000ull) {
+      if ((unsigned long long) tiles * 64ull * nChunks < 0xF0000000ull) {   // (the work counter is 32 bits; every exiting wave adds 64 more)
         const size_t needState = (size_t) tiles * 64 * 8, needProg = tiles;
         if (needState > c->pixStateWords) {
           if (c->dPixState) { HIP_TRY(hipDeviceSynchronize()); (void) hipFree(c->dPixState); c->dPixState = nullptr; c->pixStateWords = 0; }
