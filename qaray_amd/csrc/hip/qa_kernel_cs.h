@@ -994,13 +994,21 @@ __device__ __attribute__((noinline)) uint32_t csChunkRestore(const uint32_t *sta
   acc[3 * 64] = __uint_as_float((uint32_t) (s2 >> 32)); acc[4 * 64] = __uint_as_float((uint32_t) s3); acc[5 * 64] = __uint_as_float((uint32_t) (s3 >> 32));
   return (uint32_t) s0;
 }
-// ... and as this chunk leaves it (sidx with bit 31: finished)
-__device__ __attribute__((noinline)) void csChunkSave(uint32_t *state, uint32_t q, uint32_t rng, uint32_t sidx, const float *acc)
+// ... and as this chunk leaves it, every lane of the wave at once when the whole tile is between chunks (section A): the output index
+// column says what the lane holds - 0xFFFFFFFF nothing (no pixel, or one that finished in an earlier chunk), bit 31 a pixel that
+// finished in this chunk (later chunks skip it), else a pixel that goes on: RNG state, samples taken, mean, variance.  No call in
+// section E: the state is the lane's columns and its RNG register, which stay as the last sample left them.
+__device__ __attribute__((noinline)) void csChunkSaveAll(uint32_t *state, const float *acc, uint32_t rng)
 {
-  unsigned long long *st = reinterpret_cast<unsigned long long *>(state) + 4 * (size_t) q;
+  const uint32_t q = __float_as_uint(acc[13 * 64]);
+  if (q == 0xFFFFFFFFu) return;
+  unsigned long long *st = reinterpret_cast<unsigned long long *>(state) + 4 * (size_t) (q & 0x7FFFFFFFu);
 #define QA_PAIR(lo, hi) ((unsigned long long) (lo) | ((unsigned long long) (hi) << 32))
-  __hip_atomic_store(st, QA_PAIR(rng, sidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (sidx & 0x80000000u) return;
+  if (q & 0x80000000u) {
+    __hip_atomic_store(st, QA_PAIR(0u, 0x80000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  __hip_atomic_store(st, QA_PAIR(rng, __float_as_uint(acc[14 * 64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(st + 1, QA_PAIR(__float_as_uint(acc[0]), __float_as_uint(acc[64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(st + 2, QA_PAIR(__float_as_uint(acc[2 * 64]), __float_as_uint(acc[3 * 64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(st + 3, QA_PAIR(__float_as_uint(acc[4 * 64]), __float_as_uint(acc[5 * 64])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1113,7 +1121,8 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
     const unsigned long long want = __ballot(alive && needPixel);
     if (want && want == aliveMask) {
       if (CHUNK && rp.chunk_spp && curTile != 0xFFFFFFFFu) {
-        // the chunk in hand is complete: every lane's state words (agent-scope atomic stores, section E) have been waited for; publish
+        // the chunk in hand is complete: every lane stores what it holds (agent-scope atomic stores), the wave waits for them, publishes
+        csChunkSaveAll(rp.pix_state, acc, rng);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(rp.tile_progress + curTile, curChunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         curTile = 0xFFFFFFFFu;
@@ -1151,9 +1160,14 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
             if (CHUNK && rp.chunk_spp && curChunk > 0) {
               bool finished;
               const uint32_t r = csChunkRestore(rp.pix_state, QA_Q(), acc, &finished);
-              if (finished) { needSample = false; needPixel = true; }   // (finished in an earlier chunk: the lane sits this one out)
-              else rng = r;
+              if (finished) {   // (finished in an earlier chunk: the lane sits this one out)
+                needSample = false;
+                needPixel = true;
+                acc[13 * 64] = __uint_as_float(0xFFFFFFFFu);
+              } else rng = r;
             }
+          } else if (CHUNK) {
+            acc[13 * 64] = __uint_as_float(0xFFFFFFFFu);   // (a padding lane of a ragged tile holds nothing: csChunkSaveAll)
           }
         }
       }
@@ -1452,8 +1466,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       const bool more = sidx < rp.spp_min || (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
       if (more) {
         if (CHUNK && rp.chunk_spp && sidx >= chunkEnd) {
-          csChunkSave(rp.pix_state, QA_Q(), rng, (uint32_t) sidx, acc);   // the chunk's last sample of this pixel: its state waits for the next chunk's wave
-          needPixel = true;
+          needPixel = true;   // the chunk's last sample of this pixel: its state goes to the next chunk's wave when the tile is handed on (section A)
         } else {
           needSample = true;
         }
@@ -1463,7 +1476,7 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
         rp.rgb[3 * q + 1] = mean.y;
         rp.rgb[3 * q + 2] = mean.z;
         rp.ns[q] = (uint32_t) sidx;
-        if (CHUNK && rp.chunk_spp) csChunkSave(rp.pix_state, q, 0u, 0x80000000u, acc);   // (later chunks of the tile skip this pixel)
+        if (CHUNK) acc[13 * 64] = __uint_as_float(q | 0x80000000u);   // (finished: csChunkSaveAll tells the tile's later chunks)
         pixelDone = true;
         needPixel = true;
       }
