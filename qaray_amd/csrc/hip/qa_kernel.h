@@ -1723,12 +1723,19 @@ __global__ __launch_bounds__(QA_BLOCK, QA_WAVES_FOR(RES, LIGHTS)) void qa_integr
       const f3 pL = QA_GET_L();
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[QA_BLOCK], acc[2 * QA_BLOCK]);
-      f3 cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
+      f3 cstd = F3(0, 0, 0);
       const f3 dc = (pL - mean) / inv;
       mean = mean + dc;
-      if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
       acc[0] = mean.x; acc[QA_BLOCK] = mean.y; acc[2 * QA_BLOCK] = mean.z;
-      acc[3 * QA_BLOCK] = cstd.x; acc[4 * QA_BLOCK] = cstd.y; acc[5 * QA_BLOCK] = cstd.z;
+      // The running variance decides one thing - whether a pixel past sppMin takes another sample (below) - and is no output: with
+      // sppMin == sppMax (every BASELINE config) nothing reads it, and its three correctly rounded divisions per sample are not made
+      // (Cornell box + 1.5 %).  In the variants without lights only: the lit LDS-resident kernel lost 8 % to the changed register
+      // allocation around this branch (project3_sphere 18 500 -> 16 900), profiles/round03/experiments.txt 32.
+      if (LIGHTS || rp.spp_min < rp.spp_max) {
+        cstd = F3(acc[3 * QA_BLOCK], acc[4 * QA_BLOCK], acc[5 * QA_BLOCK]);
+        if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
+        acc[3 * QA_BLOCK] = cstd.x; acc[4 * QA_BLOCK] = cstd.y; acc[5 * QA_BLOCK] = cstd.z;
+      }
       ++sidx;
       if (LCOLS) acc[14 * QA_BLOCK] = __int_as_float(sidx);
       const bool more = sidx < rp.spp_min ||

@@ -1455,12 +1455,15 @@ __global__ __launch_bounds__(QA_BLOCK, TEX ? QA_CS_WAVES_TEX : QA_CS_WAVES_NOTEX
       int sidx = QA_SIDX();
       const float inv = (float) (sidx + 1);
       f3 mean = F3(acc[0], acc[64], acc[2 * 64]);
-      f3 cstd = F3(acc[3 * 64], acc[4 * 64], acc[5 * 64]);
+      f3 cstd = F3(0, 0, 0);
       const f3 dc = (QA_PL() - mean) / inv;
       mean = mean + dc;
-      if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
       acc[0] = mean.x; acc[64] = mean.y; acc[2 * 64] = mean.z;
-      acc[3 * 64] = cstd.x; acc[4 * 64] = cstd.y; acc[5 * 64] = cstd.z;
+      if (rp.spp_min < rp.spp_max) {   // (the running variance is read by the "another sample?" test below alone: qa_integrate, section E)
+        cstd = F3(acc[3 * 64], acc[4 * 64], acc[5 * 64]);
+        if (sidx > 0) cstd = cstd + ((dc * dc) * inv - cstd / (float) sidx);
+        acc[3 * 64] = cstd.x; acc[4 * 64] = cstd.y; acc[5 * 64] = cstd.z;
+      }
       ++sidx;
       acc[14 * 64] = __int_as_float(sidx);
       const bool more = sidx < rp.spp_min || (sidx < rp.spp_max && (cstd.x > 0.005f || cstd.y > 0.001f || cstd.z > 0.005f));
